@@ -1,0 +1,254 @@
+"""Generate tests/golden/*.npz by running the REAL reference modules on CPU.
+
+Runs only in the build container (needs /root/reference). The reference's files
+are imported in place, never copied; only inputs' seeds and expected OUTPUTS are
+stored. Inputs/weights are regenerated from scat_amd.synth on every machine.
+
+    python oracle/gen_golden.py [--only NAME]
+
+Two host shims are required because the reference hard-codes CUDA + network
+(models/hand_net.py:321 ``.cuda()``; models/resnet.py:194 ``model_zoo.load_url``).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = os.environ.get("SCAT_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+torch.Tensor.cuda = lambda self, *a, **k: self  # hand_net.py:321
+import torch.utils.model_zoo as _mz  # noqa: E402
+
+_mz.load_url = lambda *a, **k: {}  # resnet.py:194-195 (strict=False load of {})
+
+from scat_amd import synth  # noqa: E402
+from oracle import scat_oracle as O  # noqa: E402
+from oracle.util import digest  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+torch.manual_seed(0)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def load_strict(mod, sd):
+    missing = mod.load_state_dict(sd, strict=True)
+    return missing
+
+
+def opt_ns(**kw):
+    d = dict(vit_heads=8, pl_reg=True, iteration=3, pos_embed=True, mask_rate=0.2, vit_depth=3)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+# --------------------------------------------------------------------------
+
+def g_vt():
+    """G1/G2: vision_transformer.Transformer(784,3,8,64,392) fwd + all grads."""
+    from models import vision_transformer as VT
+
+    net = VT.Transformer(dim=784, depth=3, heads=8, dim_head=64, mlp_dim=392, dropout=0.0)
+    sd = synth.to_torch(synth.vt_state(11, "", 784, 3, 8, 64))
+    load_strict(net, sd)
+    x = T(synth.normal_like(12, "x", (2, 21, 784))).requires_grad_(True)
+    cot = T(synth.normal_like(13, "cot", (2, 21, 3)))
+    y = net(x, None)
+    (y * cot).sum().backward()
+    out = {"y": y.detach().numpy(), "dx": digest(x.grad), "dx_head": x.grad[0, :2, :8].numpy()}
+    for k, p in net.named_parameters():
+        out["g:" + k] = digest(p.grad)
+    out["g_full:layers.2.1.net.2.weight"] = net.layers[2][1].net[2].weight.grad.numpy()
+    out["g_full:layers.2.1.net.2.bias"] = net.layers[2][1].net[2].bias.grad.numpy()
+    # single attention block per dim (G1)
+    for dim in (784, 392, 196):
+        att = VT.Attention(dim, heads=8, dim_head=64, dropout=0.0)
+        asd = synth.to_torch(synth.vt_state(21, "", dim, 1, 8, 64))
+        att.load_state_dict({"to_qkv.weight": asd["layers.0.0.fn.fn.to_qkv.weight"],
+                             "to_out.0.weight": asd["layers.0.0.fn.fn.to_out.0.weight"],
+                             "to_out.0.bias": asd["layers.0.0.fn.fn.to_out.0.bias"]}, strict=True)
+        xa = T(synth.normal_like(22, f"xa{dim}", (2, 21, dim))).requires_grad_(True)
+        ya = att(xa)
+        (ya * T(synth.normal_like(23, f"ca{dim}", (2, 21, dim)))).sum().backward()
+        out[f"attn{dim}:y"] = digest(ya)
+        out[f"attn{dim}:y_head"] = ya[0, :3, :8].detach().numpy()
+        out[f"attn{dim}:dx"] = digest(xa.grad)
+        out[f"attn{dim}:dwqkv"] = digest(att.to_qkv.weight.grad)
+    np.savez(os.path.join(GOLD, "vt.npz"), **out)
+
+
+def g_bottleneck():
+    """G3: one Bottleneck(64→64→256, downsample) B=4 8×8: train fwd/bwd + running stats, eval fwd."""
+    from models import resnet as R
+
+    ds = torch.nn.Sequential(torch.nn.Conv2d(64, 256, 1, 1, bias=False), torch.nn.BatchNorm2d(256))
+    blk = R.Bottleneck(64, 64, 1, ds)
+    full = synth.resnet_state(31, "", (1, 0, 0, 0))
+    sd = {k[len("layer1.0."):]: v for k, v in synth.to_torch(full).items() if k.startswith("layer1.0.")}
+    load_strict(blk, sd)
+    x = T(synth.normal_like(32, "x", (4, 64, 8, 8))).requires_grad_(True)
+    cot = T(synth.normal_like(33, "cot", (4, 256, 8, 8)))
+    blk.train()
+    y = blk(x)
+    (y * cot).sum().backward()
+    out = {"y_train": y.detach().numpy()[:, ::37], "y_train_d": digest(y), "dx": digest(x.grad),
+           "dx_head": x.grad[0, :2].numpy()}
+    for k, p in blk.named_parameters():
+        out["g:" + k] = digest(p.grad)
+    for k, b in blk.named_buffers():
+        out["buf:" + k] = b.double().numpy()
+    blk.eval()
+    out["y_eval_d"] = digest(blk(x))
+    np.savez(os.path.join(GOLD, "bottleneck.npz"), **out)
+
+
+def g_resnet():
+    """G4: resnet50 B=2 224×224 train + eval forward."""
+    from models import resnet as R
+
+    net = R.resnet50(pretrained=True, num_classes=512)
+    load_strict(net, synth.to_torch(synth.resnet_state(41, "")))
+    x = T(synth.images(42, 2))
+    out = {}
+    for mode in ("train", "eval"):
+        net.train(mode == "train")
+        with torch.no_grad():
+            feat, x1, x2, x3, x4 = net(x)
+        out[f"{mode}:feat"] = feat.numpy()
+        for n, t in (("x1", x1), ("x2", x2), ("x3", x3), ("x4", x4)):
+            out[f"{mode}:{n}"] = digest(t, 64)
+            out[f"{mode}:{n}_chsum"] = t.double().sum(dim=(0, 2, 3)).numpy()
+        if mode == "train":
+            out["bn1.running_mean"] = net.bn1.running_mean.numpy().copy()
+            out["bn1.running_var"] = net.bn1.running_var.numpy().copy()
+            out["layer4.2.bn3.running_var"] = net.layer4[2].bn3.running_var.numpy().copy()
+    np.savez(os.path.join(GOLD, "resnet50.npz"), **out)
+
+
+def _enc(seed=51, heads=8, **kw):
+    from models.hand_net import EncoderTransformer
+
+    mp = T(synth.mean_params(seed))
+    net = EncoderTransformer(opt_ns(vit_heads=heads, **kw), mp)
+    sd = synth.to_torch(synth.encoder_transformer_state(seed, heads))
+    assert len(sd) == 356, len(sd)
+    load_strict(net, sd)
+    return net, mp
+
+
+def g_encoder():
+    """G5 + G10: full EncoderTransformer B=4, heads 8, iteration 3, pl_reg, mask .2, random.seed(3)."""
+    net, mp = _enc()
+    x = T(synth.images(52, 4))
+    lab = T(synth.labels(53, 4))
+    random.seed(3)
+    net.train()
+    pred, fv, pl = net(x)
+    loss, l3, l2, lpl = O.scat_loss(pred, lab, pl)
+    loss.backward()
+    out = {"pred": pred.detach().numpy(), "fv": digest(fv, 64), "pl": digest(pl, 64),
+           "fv_chsum": fv.detach().double().sum(dim=(0, 2, 3)).numpy(),
+           "pl_chsum": pl.detach().double().sum(dim=(0, 2, 3)).numpy(),
+           "loss": np.array([loss.item(), l3.item(), l2.item(), lpl.item()]),
+           "mpjpe": np.array(O.mpjpe_mm(pred.detach(), lab[:, :63]).item())}
+    full = ("regressor.weight", "regressor.bias", "mask_token", "conv1x1_channel_reduction.weight",
+            "transformer.layers.2.1.net.2.weight")
+    for k, p in net.named_parameters():
+        out["g:" + k] = digest(p.grad, 8)
+        if k in full:
+            out["g_full:" + k] = p.grad.numpy()
+    out["g_head:main_encoder.conv1.weight"] = net.main_encoder.conv1.weight.grad[:4].numpy()
+    # eval-mode forward too (masking still active, hand_net.py:369)
+    net2, _ = _enc()
+    net2.eval()
+    random.seed(3)
+    pe, fve, ple = net2(x)
+    out["eval:pred"] = pe.detach().numpy()
+    out["eval:fv"] = digest(fve, 64)
+    np.savez(os.path.join(GOLD, "encoder.npz"), **out)
+
+
+def g_trainstep():
+    """G6: two full train steps (reference net + torch.optim.Adam + restated train.py loss)."""
+    net, mp = _enc(seed=61)
+    optim = torch.optim.Adam(net.parameters(), lr=5e-4)
+    net.train()
+    random.seed(5)
+    out = {}
+    for step in (1, 2):
+        x = T(synth.images(62 + step, 4))
+        lab = T(synth.labels(72 + step, 4))
+        optim.zero_grad()
+        pred, fv, pl = net(x)
+        loss, l3, l2, lpl = O.scat_loss(pred, lab, pl)
+        loss.backward()
+        optim.step()
+        out[f"s{step}:loss"] = np.array([loss.item(), l3.item(), l2.item(), lpl.item()])
+        out[f"s{step}:pred"] = pred.detach().numpy()
+        out[f"s{step}:regressor.weight"] = digest(net.regressor.weight, 32)
+        out[f"s{step}:regressor.bias"] = net.regressor.bias.detach().numpy().copy()
+        out[f"s{step}:bn1.running_mean"] = net.main_encoder.bn1.running_mean.numpy().copy()
+        out[f"s{step}:conv1.weight"] = digest(net.main_encoder.conv1.weight, 32)
+        out[f"s{step}:layer3.0.conv2.weight"] = digest(net.main_encoder.layer3[0].conv2.weight, 32)
+    out["nbt"] = np.array(net.main_encoder.bn1.num_batches_tracked.item())
+    np.savez(os.path.join(GOLD, "trainstep.npz"), **out)
+
+
+def g_vit():
+    """G8a: vit.Transformer(196,3,8,64,392,0.0) on [2,128,196]."""
+    from models import vit as V
+
+    net = V.Transformer(196, 3, 8, 64, 392, 0.0)
+    load_strict(net, synth.to_torch(synth.vit_state(81, "")))
+    x = T(synth.normal_like(82, "x", (2, 128, 196))).requires_grad_(True)
+    y = net(x)
+    (y * T(synth.normal_like(83, "cot", (2, 128, 196)))).sum().backward()
+    out = {"y": digest(y, 64), "y_head": y[0, :4, :16].detach().numpy(), "dx": digest(x.grad, 64)}
+    for k, p in net.named_parameters():
+        out["g:" + k] = digest(p.grad, 8)
+    np.savez(os.path.join(GOLD, "vit.npz"), **out)
+
+
+def g_performer():
+    """G7: performer_attn_block(49,16) eval fwd/bwd on [2,21,784]."""
+    from models import vision_performer as P
+
+    blk = P.performer_attn_block(49, 16)
+    load_strict(blk, synth.to_torch(synth.performer_state(91, "")))
+    blk.eval()
+    x = T(synth.normal_like(92, "x", (2, 21, 784), std=0.5)).requires_grad_(True)
+    y = blk(x)
+    (y * T(synth.normal_like(93, "cot", (2, 21, 784)))).sum().backward()
+    out = {"y": digest(y, 64), "y_head": y[0, :4, :16].detach().numpy(), "dx": digest(x.grad, 64)}
+    for k, p in blk.named_parameters():
+        if p.grad is not None:
+            out["g:" + k] = digest(p.grad, 8)
+    np.savez(os.path.join(GOLD, "performer.npz"), **out)
+
+
+ALL = {"vt": g_vt, "bottleneck": g_bottleneck, "resnet": g_resnet, "encoder": g_encoder,
+       "trainstep": g_trainstep, "vit": g_vit, "performer": g_performer}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    for name, fn in ALL.items():
+        if a.only and a.only != name:
+            continue
+        print("golden:", name, flush=True)
+        fn()
+    print("done")

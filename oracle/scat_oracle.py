@@ -1,0 +1,270 @@
+"""CPU oracle for the SCAT reg_transformer hot path — TEST INFRASTRUCTURE ONLY.
+
+A functional (state_dict-keyed) PyTorch-CPU fp32 restatement of the reference's
+arithmetic. Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this; the product (``scat_amd``) never does.
+
+Pinned: ``oracle/gen_golden.py`` runs the real reference modules (imported from
+/root/reference in the build container) on tensors from ``scat_amd.synth`` and
+stores their outputs in ``tests/golden``; ``tests/test_oracle_golden.py`` checks
+this restatement against those files.
+
+Every function cites the reference lines it follows (paths relative to the
+reference checkout).
+"""
+from __future__ import annotations
+
+import math
+import random
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+BN_MOM = 0.1
+LN_EPS = 1e-5
+
+
+# --------------------------------------------------------------------------
+# backbone — models/resnet.py
+# --------------------------------------------------------------------------
+
+def batch_norm(sd, key, x, training):
+    """nn.BatchNorm2d as used at models/resnet.py:68-73,108 (momentum .1, eps 1e-5).
+    Train mode normalises with batch stats and updates running stats in ``sd`` in place."""
+    rm, rv = sd[key + ".running_mean"], sd[key + ".running_var"]
+    y = F.batch_norm(x, rm, rv, sd[key + ".weight"], sd[key + ".bias"], training, BN_MOM, BN_EPS)
+    if training and (key + ".num_batches_tracked") in sd:
+        sd[key + ".num_batches_tracked"] += 1
+    return y
+
+
+def bottleneck(sd, key, x, stride, training):
+    """Bottleneck.forward, models/resnet.py:78-98 (stride on the 3x3, :69)."""
+    out = F.conv2d(x, sd[key + ".conv1.weight"])
+    out = F.relu(batch_norm(sd, key + ".bn1", out, training))
+    out = F.conv2d(out, sd[key + ".conv2.weight"], stride=stride, padding=1)
+    out = F.relu(batch_norm(sd, key + ".bn2", out, training))
+    out = F.conv2d(out, sd[key + ".conv3.weight"])
+    out = batch_norm(sd, key + ".bn3", out, training)
+    if (key + ".downsample.0.weight") in sd:
+        res = F.conv2d(x, sd[key + ".downsample.0.weight"], stride=stride)
+        res = batch_norm(sd, key + ".downsample.1", res, training)
+    else:
+        res = x
+    return F.relu(out + res)
+
+
+def resnet_forward(sd, x, prefix="", training=True):
+    """ResNet.forward, models/resnet.py:142-162 → (feat[B,1024], x1, x2, x3, x4)."""
+    p = prefix
+    x = F.conv2d(x, sd[p + "conv1.weight"], stride=2, padding=3)
+    x = F.relu(batch_norm(sd, p + "bn1", x, training))
+    x = F.max_pool2d(x, 3, 2, 1)
+    feats = []
+    for li in range(4):
+        bi = 0
+        while f"{p}layer{li + 1}.{bi}.conv1.weight" in sd:
+            stride = 2 if (li > 0 and bi == 0) else 1
+            x = bottleneck(sd, f"{p}layer{li + 1}.{bi}", x, stride, training)
+            bi += 1
+        feats.append(x)
+    x = F.avg_pool2d(feats[3], 7, 1)
+    x = F.relu(x.reshape(x.size(0), -1))
+    x = F.relu(F.linear(x, sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
+    return (x, *feats)
+
+
+# --------------------------------------------------------------------------
+# token mixers
+# --------------------------------------------------------------------------
+
+def attention(x, w_qkv, w_out, b_out, heads, scale):
+    """Attention.forward, models/vision_transformer.py:59-79 (mask is always None,
+    models/hand_net.py:375). Returns (out, attn[B,h,n,n])."""
+    b, n, _ = x.shape
+    qkv = F.linear(x, w_qkv)
+    inner = qkv.shape[-1] // 3
+    d = inner // heads
+    q, k, v = (t.reshape(b, n, heads, d).permute(0, 2, 1, 3) for t in qkv.split(inner, dim=-1))
+    dots = torch.matmul(q, k.transpose(-1, -2)) * scale
+    attn = dots.softmax(dim=-1)
+    out = torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(b, n, inner)
+    return F.linear(out, w_out, b_out), attn
+
+
+def vt_forward(sd, x, prefix, depth=3, heads=8, dim_head=64):
+    """vision_transformer.Transformer.forward, models/vision_transformer.py:81-101:
+    x += Attn(LN x); non-last: x = FF(LN x) (dim halves); last: x = FF_last(x) (no LN)."""
+    scale = dim_head ** -0.5
+    for l in range(depth):
+        k = f"{prefix}layers.{l}"
+        dim = x.shape[-1]
+        h = F.layer_norm(x, (dim,), sd[k + ".0.fn.norm.weight"], sd[k + ".0.fn.norm.bias"], LN_EPS)
+        a, _ = attention(h, sd[k + ".0.fn.fn.to_qkv.weight"], sd[k + ".0.fn.fn.to_out.0.weight"],
+                         sd[k + ".0.fn.fn.to_out.0.bias"], heads, scale)
+        x = a + x
+        if l == depth - 1:
+            f = "%s.1.net" % k
+            h = x
+        else:
+            f = "%s.1.fn.net" % k
+            h = F.layer_norm(x, (dim,), sd[k + ".1.norm.weight"], sd[k + ".1.norm.bias"], LN_EPS)
+        h = F.gelu(F.linear(h, sd[f + ".0.weight"], sd[f + ".0.bias"]))
+        x = F.linear(h, sd[f + ".2.weight"], sd[f + ".2.bias"])
+    return x
+
+
+def vit_forward(sd, x, prefix, depth=3, heads=8):
+    """vit.Transformer.forward, models/vit.py:71-84: x = Attn(x)+x; x = FF(x)+x;
+    no LayerNorm; scale = dim**-0.5 (models/vit.py:41). Dropout p=0."""
+    scale = x.shape[-1] ** -0.5
+    for l in range(depth):
+        k = f"{prefix}layers.{l}"
+        a, _ = attention(x, sd[k + ".0.fn.to_qkv.weight"], sd[k + ".0.fn.to_out.0.weight"],
+                         sd[k + ".0.fn.to_out.0.bias"], heads, scale)
+        x = a + x
+        h = F.gelu(F.linear(x, sd[k + ".1.fn.net.0.weight"], sd[k + ".1.fn.net.0.bias"]))
+        x = F.linear(h, sd[k + ".1.fn.net.3.weight"], sd[k + ".1.fn.net.3.bias"]) + x
+    return x
+
+
+def performer_block(sd, x, prefix, emb_s, head):
+    """performer_attn_block.forward in eval mode (dropout off),
+    models/vision_performer.py:34-68. Split order k, q, v (:47)."""
+    emb = emb_s * head
+    w = sd[prefix + "w"]
+    m = w.shape[0]
+
+    def prm_exp(t):  # :34-43
+        xd = (t * t).sum(dim=-1, keepdim=True) / 2
+        return torch.exp(t @ w.t() - xd) / math.sqrt(m)
+
+    h = F.layer_norm(x, (emb,), sd[prefix + "ln1.weight"], sd[prefix + "ln1.bias"], LN_EPS)
+    outs = []
+    for t in h.split(emb_s, dim=-1):  # :59-60
+        k, q, v = F.linear(t, sd[prefix + "kqv.weight"], sd[prefix + "kqv.bias"]).split(emb_s, dim=-1)
+        kp, qp = prm_exp(k), prm_exp(q)
+        D = (qp * kp.sum(dim=1, keepdim=True)).sum(dim=-1, keepdim=True)  # :49
+        kptv = torch.einsum("bin,bim->bnm", v, kp)  # :50
+        outs.append(torch.einsum("bti,bni->btn", qp, kptv) / D)  # :52
+    x = x + F.linear(torch.cat(outs, dim=-1), sd[prefix + "proj.weight"], sd[prefix + "proj.bias"])
+    h = F.layer_norm(x, (emb,), sd[prefix + "ln2.weight"], sd[prefix + "ln2.bias"], LN_EPS)
+    h = F.gelu(F.linear(h, sd[prefix + "mlp.0.weight"], sd[prefix + "mlp.0.bias"]))
+    return x + F.linear(h, sd[prefix + "mlp.2.weight"], sd[prefix + "mlp.2.bias"])
+
+
+# --------------------------------------------------------------------------
+# model — models/hand_net.py:315-398
+# --------------------------------------------------------------------------
+
+def mask_indices(mask_rate, full_content=21):
+    """models/hand_net.py:369-372 — consumes python ``random`` exactly like the reference."""
+    if 0.1 <= mask_rate <= 0.9:
+        masked = list(range(full_content))
+        random.shuffle(masked)
+        return masked[: int(mask_rate * full_content)]
+    return []
+
+
+def encoder_transformer_forward(sd, mean_params, x, heads=8, iteration=3, pos_embed=True,
+                                mask_rate=0.2, pl_reg=True, training=True, masked=None):
+    """EncoderTransformer.forward, models/hand_net.py:355-398."""
+    feat1024, x1, x2, x3, x4 = resnet_forward(sd, x, "main_encoder.", training)
+    feat_visual = F.conv2d(x2, sd["conv1x1_channel_reduction.weight"])  # :363
+    b = feat_visual.size(0)
+    feat = feat_visual.reshape(b, 21, -1)
+    if pos_embed:
+        feat = feat + sd["positionalEncoding.pe"][: feat.size(0)]  # :74-75 (slices dim 0 of [1,21,784])
+    if masked is None:
+        masked = mask_indices(mask_rate)
+    if len(masked):
+        feat = feat.clone()
+        feat[:, masked, :] = sd["mask_token"]  # :373
+    feat_out = vt_forward(sd, feat, "transformer.", 3, heads, 64).reshape(b, -1)  # :375-377
+    pred = mean_params.repeat(b, 1).clone()
+    pred[:, 3:] = pred[:, 3:] + feat_out  # :383
+    for _ in range(iteration):  # :385-387
+        pred = pred + F.linear(torch.cat((feat1024, pred), dim=1), sd["regressor.weight"], sd["regressor.bias"])
+    j = pred[:, 3:66].reshape(-1, 21, 3)
+    j = j - j[:, 1:2, :]  # :389-391
+    pred = torch.cat((pred[:, :3], j.reshape(-1, 63)), dim=1)
+    if pl_reg:
+        pl = torch.autograd.grad(feat_out.sum(), feat_visual, retain_graph=True)[0]  # :396
+        return pred, feat_visual, pl
+    return pred, feat_visual
+
+
+# --------------------------------------------------------------------------
+# train step — train.py:112-120,158-209
+# --------------------------------------------------------------------------
+
+def scat_loss(outputs, labels, pl_term=None, w3d=100000.0, w2d=10.0):
+    """train.py:165-203. Returns (loss, l_3d, l_2d, l_pl)."""
+    cam = outputs[:, :3].reshape(-1, 1, 3)
+    j3 = outputs[:, 3:66].reshape(-1, 21, 3)
+    xt = j3[:, :, :2] + cam[:, :, 1:]  # :115
+    j2 = (cam[:, :, 0] * xt.reshape(xt.size(0), -1)).reshape(xt.size(0), 21, 2) * 112 + 112  # :116-120
+    if pl_term is not None:  # :178-183
+        pl_len = pl_term.square().sum(dim=[2, 3]).mean(dim=[1]).sqrt()
+        pl_mean = 0.0 + 0.01 * (pl_len.mean() - 0.0)
+        l_pl = (pl_len - pl_mean).square().mean()
+    else:
+        l_pl = torch.zeros((), dtype=outputs.dtype)
+    if labels.size(1) == 105:  # :188-192
+        g3, g2 = labels[:, :63], labels[:, 63:]
+    else:  # :193-198
+        g3, g2 = labels[:, 61:124], labels[:, 124:]
+    l3 = F.mse_loss(j3.reshape(-1, 63), g3)
+    l2 = F.l1_loss(j2.reshape(-1, 42), g2)
+    loss = w3d * l3 + w2d * l2
+    if pl_term is not None:
+        loss = loss + 10 * l_pl
+    return loss, l3, l2, l_pl
+
+
+def mpjpe_mm(pred66, gt63):
+    """3-D MPJPE in mm, eval.py:753 formula."""
+    p = pred66[:, 3:66].reshape(-1, 21, 3)
+    g = gt63.reshape(-1, 21, 3)
+    return (p - g).norm(dim=-1).mean() * 1000.0
+
+
+PARAM_SKIP = ("running_mean", "running_var", "num_batches_tracked", "positionalEncoding.pe")
+
+
+def trainable(sd):
+    return OrderedDict((k, v) for k, v in sd.items() if not k.endswith(PARAM_SKIP))
+
+
+def adam_update(params, grads, state, lr, step, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults (train.py:60), single-tensor formula."""
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    for k in params:
+        g = grads[k]
+        m, v = state.setdefault(k, (torch.zeros_like(g), torch.zeros_like(g)))
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        params[k].addcdiv_(m, denom, value=-lr / bc1)
+
+
+def train_step(sd, mean_params, x, labels, adam_state, step, lr=5e-4, masked=None, **kw):
+    """One Trainer.train inner iteration (train.py:154-209): forward, loss, backward, Adam.
+    ``sd`` tensors are updated in place. Returns dict of scalars + grads."""
+    params = trainable(sd)
+    for p in params.values():
+        p.requires_grad_(True)
+    out = encoder_transformer_forward(sd, mean_params, x, masked=masked, **kw)
+    pl = out[2] if len(out) == 3 else None
+    loss, l3, l2, lpl = scat_loss(out[0], labels, pl)
+    grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+    grads = OrderedDict((k, g if g is not None else torch.zeros_like(p))
+                        for (k, p), g in zip(params.items(), grads))
+    with torch.no_grad():
+        for p in params.values():
+            p.requires_grad_(False)
+        adam_update(params, grads, adam_state, lr, step)
+    return {"loss": loss.detach(), "l3d": l3.detach(), "l2d": l2.detach(), "lpl": lpl.detach(),
+            "pred": out[0].detach(), "feat_visual": out[1].detach(), "pl": pl, "grads": grads}
