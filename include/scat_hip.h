@@ -1,0 +1,145 @@
+/* libscat_hip — C ABI of the MI355X (gfx950) SCAT hot path.
+ *
+ * Every function: plain pointers to DEVICE memory owned by the caller (PyTorch-ROCm
+ * allocations, passed as tensor.data_ptr()), explicit int sizes, a caller-provided
+ * workspace where one is needed, and a hipStream_t passed as void*.  Stream-ordered,
+ * never synchronises, never allocates, retains no pointer.  Returns 0 or a negative
+ * SCAT_E_* code; scat_last_error() gives the thread-local message.  fp32 everywhere.
+ *
+ * Each entry point names the reference call it stands in for (paths relative to the
+ * reference checkout tomguluson92/SCAT).  The reference has no FFI of its own (it is pure
+ * torch.nn); the binding a maintainer adds is the ctypes stub in INTEGRATION.md.
+ */
+#ifndef SCAT_HIP_H
+#define SCAT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCAT_OK 0
+#define SCAT_E_SHAPE (-1)     /* bad / unsupported dimensions */
+#define SCAT_E_ARG (-2)       /* null pointer, bad flag */
+#define SCAT_E_WORKSPACE (-3) /* workspace too small */
+#define SCAT_E_LAUNCH (-4)    /* hipError at launch (message carries hipGetErrorString) */
+#define SCAT_E_ARCH (-5)      /* not a gfx950 device */
+
+int scat_version(void);
+const char* scat_last_error(void);
+/* 0 if the current device is gfx950, else SCAT_E_ARCH. */
+int scat_check_device(void);
+
+/* ---- convolution: nn.Conv2d(bias=False) at models/resnet.py:65-72,105,129; hand_net.py:329 ----
+ * x[B,Cin,H,W] NCHW, w[Cout,Cin,KH,KW], y[B,Cout,OH,OW]; KH=KW in {1,3,7}, stride in {1,2}.
+ * in_scale/in_shift (per input channel, nullable) + in_relu fuse the PREVIOUS BatchNorm(+ReLU)
+ * into the operand load: the conv sees relu(x*scale+shift); zero padding stays zero. */
+int scat_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
+                    int Cout, int KH, int KW, int stride, int pad, const float* in_scale, const float* in_shift,
+                    int in_relu, void* stream);
+/* dx[B,Cin,H,W] (+)= conv_transpose(dy[B,Cout,OH,OW], w).  wt = scat_conv2d_wt() output. */
+int scat_conv2d_dgrad(const float* dy, const float* wt, float* dx, int B, int Cin, int H, int W, int Cout, int KH,
+                      int KW, int stride, int pad, int accumulate, void* stream);
+/* wt[Cin][Cout*KH*KW] = w[Cout][Cin][KH][KW] re-laid for the data-gradient contraction. */
+int scat_conv2d_wt(const float* w, float* wt, int Cout, int Cin, int KH, int KW, void* stream);
+/* dw[Cout,Cin,KH,KW] = sum over pixels dy * relu(x*scale+shift).  Deterministic two-stage
+ * split-K (no float atomics).  ws: scat_conv2d_wgrad_ws() bytes. */
+int64_t scat_conv2d_wgrad_ws(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad);
+int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout, int KH,
+                      int KW, int stride, int pad, const float* in_scale, const float* in_shift, int in_relu,
+                      void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- generic fp32 GEMM: nn.Linear / einsum at models/vision_transformer.py:33-35,55-57,61,75;
+ *      models/resnet.py:116; hand_net.py:353 ----
+ * C[M,N] (+)= op(A)[M,K] * op(B)[K,N] (+ bias).  A(i,k) = a[i*a_si + k*a_sk], B(k,j) = b[k*b_sk + j*b_sj],
+ * C(i,j) = c[i*c_si + j*c_sj]; one of each stride pair must be 1.  bias_mode 0 none, 1 bias[i], 2 bias[j].
+ * ws may be NULL (no split-K). */
+int64_t scat_gemm_ws(int M, int N, int K);
+int scat_gemm(const float* a, int64_t a_si, int64_t a_sk, const float* b, int64_t b_sk, int64_t b_sj, float* c,
+              int64_t c_si, int64_t c_sj, int M, int N, int K, const float* bias, int bias_mode, int accumulate,
+              void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- BatchNorm2d, training + inference: models/resnet.py:68-73,108,131 (eps 1e-5, momentum .1) ----
+ * stats: per-channel batch mean / biased variance (fp64 accumulation, fixed reduction order), folded
+ * into scale = gamma*invstd, shift = beta - mean*scale; running stats updated (unbiased var).
+ * ws: scat_bn_ws(C) bytes. save_mean / save_invstd [C] are kept for backward. */
+int64_t scat_bn_ws(int B, int C, int HW);
+int scat_bn_train_stats(const float* x, int B, int C, int HW, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                        float* save_invstd, float* scale, float* shift, void* ws, int64_t ws_bytes, void* stream);
+/* inference: scale/shift from running stats */
+int scat_bn_eval_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, int C, float* scale, float* shift, void* stream);
+/* y = [relu]( x*scale[c] + shift[c] [+ residual] ) */
+int scat_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, int relu, float* y,
+                  int B, int C, int HW, void* stream);
+/* backward of y = [relu](bn(x) [+res]):  g = dy * (mask);  mask from y_out>0 (if y_out) else from
+ * x*scale+shift>0 (if relu) else 1.  Produces dgamma, dbeta, dx and (if dres) dres (+)= g. */
+int scat_bn_bwd(const float* dy, const float* x, const float* y_out, int relu, const float* scale,
+                const float* shift, const float* save_mean, const float* save_invstd, const float* gamma,
+                float* dgamma, float* dbeta, float* dx, float* dres, int dres_accumulate, int B, int C, int HW,
+                void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- pooling: models/resnet.py:110 (MaxPool2d(3,2,1)), :115 (AvgPool2d(7)) ----
+ * max-pool reads relu(x*scale+shift) when scale != NULL (stem BN fused); idx = argmax tap (int8). */
+int scat_maxpool3x3s2_fwd(const float* x, const float* scale, const float* shift, int relu, float* y, int8_t* idx,
+                          int B, int C, int H, int W, void* stream);
+int scat_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* dx, int B, int C, int H, int W, void* stream);
+/* global average over HW then relu: y[B,C] */
+int scat_avgpool_fwd(const float* x, float* y, int B, int C, int HW, int relu, void* stream);
+int scat_avgpool_bwd(const float* dy, const float* y, int relu, float* dx, int B, int C, int HW, int accumulate,
+                     void* stream);
+
+/* ---- LayerNorm over the last dim (eps 1e-5): models/vision_transformer.py:20-26 ---- */
+int scat_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       int rows, int dim, float eps, void* stream);
+int64_t scat_layernorm_bwd_ws(int rows, int dim);
+int scat_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                       float* dx, float* dgamma, float* dbeta, int rows, int dim, void* ws, int64_t ws_bytes,
+                       void* stream);
+
+/* ---- attention core: models/vision_transformer.py:61-76 / models/vit.py:51-66 ----
+ * qkv[B,n,3*h*d] (q|k|v, each 'b n (h d)'), out[B,n,h*d], attn[B,h,n,n] (saved softmax). n <= 128, d = 64. */
+int scat_attention_fwd(const float* qkv, float* out, float* attn, int B, int n, int heads, int dim_head, float scale,
+                       void* stream);
+int scat_attention_bwd(const float* dout, const float* qkv, const float* attn, float* dqkv, int B, int n, int heads,
+                       int dim_head, float scale, void* stream);
+
+/* ---- elementwise ---- */
+/* exact-erf GELU (nn.GELU default), models/vision_transformer.py:34 */
+int scat_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int scat_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+int scat_relu_fwd(const float* x, float* y, int64_t n, void* stream);
+int scat_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+/* y = a + alpha*b */
+int scat_axpy(const float* a, const float* b, float alpha, float* y, int64_t n, void* stream);
+/* column sums: out[j] (+)= sum_i x[i*cols + j]  (bias gradients), fixed order */
+int scat_colsum(const float* x, float* out, int rows, int cols, int accumulate, void* stream);
+/* tokens: y[B,T,D] = x[B,T,D] + pe[T,D], then rows t in masked[] <- mask_token[D]   (hand_net.py:366-373) */
+int scat_tokens_fwd(const float* x, const float* pe, const float* mask_token, const int32_t* masked, int nmasked,
+                    float* y, int B, int T, int D, void* stream);
+int scat_tokens_bwd(const float* dy, const int32_t* masked, int nmasked, float* dx, float* dmask_token, int B, int T,
+                    int D, void* stream);
+
+/* ---- head: regressor loop + root-relative (hand_net.py:379-393) ----
+ * pred0[b] = mean[66]; pred0[:,3:] += feat_out[b,63]; iter x: pred += [feat1024,pred]·W^T + bias; joints -= joint1.
+ * preds[(iters+1),B,66] keeps every iterate for backward; out[B,66]. */
+int scat_regressor_fwd(const float* feat, const float* feat_out, const float* mean, const float* w, const float* bias,
+                       float* preds, float* out, int B, int F, int P, int iters, void* stream);
+int scat_regressor_bwd(const float* dout, const float* feat, const float* preds, const float* w, float* dfeat,
+                       float* dfeat_out, float* dw, float* dbias, int B, int F, int P, int iters, void* ws,
+                       int64_t ws_bytes, void* stream);
+int64_t scat_regressor_bwd_ws(int B, int F, int P, int iters);
+
+/* ---- loss: train.py:165-203 (orthographic projection *112+112, MSE 3-D, L1 2-D) ----
+ * out[B,66], gt3d[B,63] / gt2d[B,42] with row stride ld_gt; losses[3] = {loss, l3d, l2d}; dout[B,66]. */
+int scat_loss_fwd_bwd(const float* out, const float* gt3d, const float* gt2d, int ld_gt, float w3d, float w2d,
+                      float* losses, float* dout, int B, void* stream);
+
+/* ---- Adam (torch.optim.Adam defaults, train.py:60): one launch over a flat parameter bucket ---- */
+int scat_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+              int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

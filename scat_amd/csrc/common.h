@@ -1,0 +1,57 @@
+// Shared host/device helpers for libscat_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/scat_hip.h"
+
+namespace scat {
+
+void set_error(const char* fmt, ...);
+
+// Every entry point returns through these: no exception crosses the C boundary.
+#define SCAT_REQUIRE(cond, code, ...)          \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::scat::set_error(__VA_ARGS__);    \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+#define SCAT_LAUNCH_CHECK(name)                                                        \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) {                                                       \
+            ::scat::set_error("%s: launch failed: %s", name, hipGetErrorString(e__));  \
+            return SCAT_E_LAUNCH;                                                      \
+        }                                                                              \
+    } while (0)
+
+// Unsigned division by a runtime-constant divisor, valid for n < 2^31
+// (Granlund–Montgomery add-shift form): q = (umulhi(n, mul) + n) >> shift.
+struct FastDiv {
+    uint32_t mul, shift, d;
+    __host__ static FastDiv make(uint32_t d) {
+        FastDiv f;
+        f.d = d;
+        uint32_t s = 0;
+        while ((1ull << s) < d) ++s;
+        f.shift = s;
+        f.mul = (uint32_t)((((1ull << s) - d) << 32) / d + 1);
+        return f;
+    }
+    __host__ __device__ __forceinline__ uint32_t div(uint32_t n) const {
+#ifdef __HIP_DEVICE_COMPILE__
+        return (__umulhi(n, mul) + n) >> shift;
+#else
+        return (uint32_t)(((((uint64_t)n * mul) >> 32) + n) >> shift);
+#endif
+    }
+};
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+static inline bool fits_i32(int64_t n) { return n >= 0 && n < (1ll << 31); }
+
+}  // namespace scat

@@ -1,0 +1,335 @@
+// fp32 MFMA contraction engine for gfx950 (MI355X).
+//
+// One workgroup = 256 threads = 4 wavefronts (64 lanes) computing a BM x BN tile of
+//     C[i][j] = sum_k A(i,k) * B(k,j)
+// with v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD — the chip's fp32
+// peak; there is no xf32/TF32 on gfx950).  Operands are staged HBM -> registers -> LDS as
+// k-major tiles  T[k][i]  (row stride BI+4 floats), so the MFMA operand fetch
+// "lane l wants X[i = l&31][k = l>>5]" is one conflict-free ds_read_b32 per 32-lane half.
+// Staging is register double-buffered: the global loads of K-step t+1 are in flight while
+// the MFMAs of K-step t issue; one s_barrier per K-step.
+//
+// The two operands come from "loaders":
+//   MatLoader     - a strided matrix (weights, Linear activations, split-K slabs)
+//   GatherLoader  - an NCHW feature map seen through conv index arithmetic
+//                   (im2col on the fly; zero padding; optional fused per-channel
+//                   scale/shift/ReLU = the previous BatchNorm applied in the consumer's
+//                   prologue).  The same loader serves forward (pixel = tile column),
+//                   data-gradient (transposed-conv arithmetic, stride 1 or 2) and
+//                   weight-gradient (pixel = contraction index).
+//
+// Reference semantics replaced: torch.nn.Conv2d / nn.Linear as called from
+// models/resnet.py:62-98,103-162 and models/vision_transformer.py:28-79 (fp32).
+#pragma once
+#include "common.h"
+
+namespace scat {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NT = 256;   // threads per workgroup
+constexpr int LPAD = 4;   // LDS row padding (floats): k-fast writes become <=2-way, rows stay 16-B aligned
+
+// ---------------------------------------------------------------- descriptors
+
+struct MatDesc {          // elem(i,k) = p[z*sz + i*si + k*sk]
+    const float* p;
+    int64_t si, sk, sz;
+    int I, K;
+};
+
+struct GatherDesc {       // elem(pix, ct) of an NCHW tensor through conv arithmetic
+    const float* p;
+    const float* scale;   // optional per-source-channel fused transform (nullptr = identity)
+    const float* shift;
+    int relu;
+    int C, H, W;          // source tensor: [Nimg][C][H][W]
+    int PH, PW;           // pixel grid the GEMM index runs over
+    int a, b, c0;         // source row  t = y*a + kh*b + c0  (columns alike)
+    int npix;             // Nimg*PH*PW
+    int nct;              // C*KH*KW
+    FastDiv dPHW, dPW;
+};
+
+struct OutDesc {
+    float* p;
+    int mode;             // 0: C[z*sz + i*si + j*sj]   1: NCHW, j = pixel: [(j/HW)][i][j%HW]
+    int64_t si, sj, sz;
+    int I, J;
+    int C, HW;
+    FastDiv dHW;
+    const float* bias;    // optional
+    int bias_mode;        // 1: bias[i]  2: bias[j]
+    int accumulate;       // C += result
+};
+
+// ---------------------------------------------------------------- loaders
+
+template <int BI, int BK, bool KFAST>
+struct MatLoader {
+    static constexpr int NE = BI * BK / NT;
+    using Desc = MatDesc;
+    float v[NE];
+    int i_t, k_t;
+    const float* base;
+
+    __device__ __forceinline__ void init(const MatDesc& d, int i0, int z) {
+        const int tid = threadIdx.x;
+        if (KFAST) { k_t = tid % BK; i_t = tid / BK; }
+        else       { i_t = tid % BI; k_t = tid / BI; }
+        base = d.p + (int64_t)z * d.sz;
+        i_t += i0;
+    }
+    __device__ __forceinline__ void load(const MatDesc& d, int k0, int kend) {
+#pragma unroll
+        for (int r = 0; r < NE; ++r) {
+            int i = i_t + (KFAST ? r * (NT / BK) : 0);
+            int k = k0 + k_t + (KFAST ? 0 : r * (NT / BI));
+            bool ok = (i < d.I) && (k < kend);
+            v[r] = ok ? base[(int64_t)i * d.si + (int64_t)k * d.sk] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, int i0) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int r = 0; r < NE; ++r) {
+            int il = KFAST ? tid / BK + r * (NT / BK) : tid % BI;
+            int kl = KFAST ? tid % BK : tid / BI + r * (NT / BI);
+            lds[kl * (BI + LPAD) + il] = v[r];
+        }
+    }
+};
+
+// Conv-arithmetic loader. KH,KW compile-time so tap decode is mul-shift. D2 = divisor 2
+// (data-gradient of a stride-2 conv: only taps of matching parity contribute).
+template <int BI, int BK, int KH, int KW, bool D2, bool PIXK>
+struct GatherLoader {
+    static constexpr int KK = KH * KW;
+    static constexpr int NE = BI * BK / NT;
+    using Desc = GatherDesc;
+    float v[NE];
+    // pixel-side state (per tile when !PIXK, per K-step when PIXK)
+    int pixoff;
+    uint64_t mask;
+    // ct-side state when PIXK (fixed per tile)
+    int ctoff[PIXK ? NE : 1];
+    int ctc[PIXK ? NE : 1];
+    int cttap[PIXK ? NE : 1];   // -1 = out of range
+    int idx0;                   // first i (pixel when !PIXK, ct when PIXK)
+
+    static __device__ __forceinline__ int tap_off(const GatherDesc& d, int tap) {
+        int kh = tap / KW, kw = tap - kh * KW;
+        if (D2) return -((kh >> 1) * d.W + (kw >> 1));
+        return (kh * d.W + kw) * d.b;
+    }
+
+    __device__ __forceinline__ void decode_pix(const GatherDesc& d, int pix) {
+        mask = 0;
+        pixoff = 0;
+        if (pix >= d.npix) return;
+        uint32_t n = d.dPHW.div((uint32_t)pix);
+        uint32_t r = pix - n * (d.PH * d.PW);
+        uint32_t y = d.dPW.div(r);
+        uint32_t x = r - y * d.PW;
+        int ty0 = (int)y * d.a + d.c0, tx0 = (int)x * d.a + d.c0;
+        uint32_t rowm = 0, colm = 0;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            int t = ty0 + kh * d.b;
+            bool ok = D2 ? (t >= 0 && !(t & 1) && (t >> 1) < d.H) : ((unsigned)t < (unsigned)d.H);
+            rowm |= (ok ? 1u : 0u) << kh;
+        }
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+            int t = tx0 + kw * d.b;
+            bool ok = D2 ? (t >= 0 && !(t & 1) && (t >> 1) < d.W) : ((unsigned)t < (unsigned)d.W);
+            colm |= (ok ? 1u : 0u) << kw;
+        }
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+            if ((rowm >> kh) & 1u) mask |= (uint64_t)colm << (kh * KW);
+        pixoff = (int)n * d.C * d.H * d.W + (D2 ? ((ty0 >> 1) * d.W + (tx0 >> 1)) : (ty0 * d.W + tx0));
+    }
+
+    __device__ __forceinline__ void init(const GatherDesc& d, int i0, int /*z*/) {
+        const int tid = threadIdx.x;
+        idx0 = i0;
+        if (!PIXK) {
+            decode_pix(d, i0 + tid % BI);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NE; ++r) {
+                int ct = i0 + tid / BK + r * (NT / BK);
+                int c = ct / KK, tap = ct - c * KK;
+                bool ok = ct < d.nct;
+                ctc[r] = ok ? c : 0;
+                cttap[r] = ok ? tap : -1;
+                ctoff[r] = c * d.H * d.W + tap_off(d, tap);
+            }
+        }
+    }
+
+    __device__ __forceinline__ float fetch(const GatherDesc& d, int off, int c, bool ok) const {
+        float x = 0.f;
+        if (ok) {
+            x = d.p[off];
+            if (d.scale) x = fmaf(x, d.scale[c], d.shift[c]);
+            if (d.relu) x = fmaxf(x, 0.f);
+        }
+        return x;
+    }
+
+    __device__ __forceinline__ void load(const GatherDesc& d, int k0, int kend) {
+        const int tid = threadIdx.x;
+        if (!PIXK) {
+#pragma unroll
+            for (int r = 0; r < NE; ++r) {
+                int ct = k0 + tid / BI + r * (NT / BI);
+                int c = ct / KK, tap = ct - c * KK;
+                bool ok = (ct < kend) && ((mask >> tap) & 1ull);
+                v[r] = fetch(d, pixoff + c * d.H * d.W + tap_off(d, tap), c, ok);
+            }
+        } else {
+            int pix = k0 + tid % BK;
+            decode_pix(d, pix < kend ? pix : d.npix);
+#pragma unroll
+            for (int r = 0; r < NE; ++r) {
+                bool ok = (cttap[r] >= 0) && ((mask >> (cttap[r] & 63)) & 1ull);
+                v[r] = fetch(d, pixoff + ctoff[r], ctc[r], ok);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float* lds, int /*i0*/) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int r = 0; r < NE; ++r) {
+            int il = PIXK ? tid / BK + r * (NT / BK) : tid % BI;
+            int kl = PIXK ? tid % BK : tid / BI + r * (NT / BI);
+            lds[kl * (BI + LPAD) + il] = v[r];
+        }
+    }
+};
+
+// ---------------------------------------------------------------- kernel
+
+// XCD-aware, bijective remap of the linear workgroup id: the 8 XCDs (private L2 each) get
+// contiguous chunks of the tile list, so workgroups that share an operand panel hit one L2.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    int q = n >> 3, r = n & 7, x = id & 7, s = id >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+
+template <class LA, class LB, int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename LB::Desc db, OutDesc dc,
+                                                  int M, int N, int K, int kchunk) {
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+    static_assert(WM * WN == 4 && MI >= 1 && NI >= 1, "wave layout");
+    constexpr int SA = BM + LPAD, SB = BN + LPAD;
+    __shared__ float lds[2 * BK * (SA + SB)];
+    // layout: A buffers 0,1 then B buffers 0,1
+    auto As = [&](int buf) -> float* { return lds + buf * (BK * SA); };
+    auto Bs = [&](int buf) -> float* { return lds + 2 * BK * SA + buf * (BK * SB); };
+
+    const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int i0 = (tile % mt) * BM, j0 = (tile / mt) * BN;   // m fastest: neighbours share the B panel
+    const int z = blockIdx.z;
+    const int kbeg = z * kchunk, kend = min(K, kbeg + kchunk);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    LA la;
+    LB lb;
+    la.init(da, i0, z);
+    lb.init(db, j0, z);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        la.load(da, kbeg, kend);
+        lb.load(db, kbeg, kend);
+        la.store(As(0), i0);
+        lb.store(Bs(0), j0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            la.load(da, kbeg + (kt + 1) * BK, kend);
+            lb.load(db, kbeg + (kt + 1) * BK, kend);
+        }
+        const float* as = As(cur) + wm * (BM / WM) + l31;
+        const float* bs = Bs(cur) + wn * (BN / WN) + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[MI], bv[NI];
+#pragma unroll
+            for (int a = 0; a < MI; ++a) av[a] = as[(kk + lh) * SA + a * 32];
+#pragma unroll
+            for (int b = 0; b < NI; ++b) bv[b] = bs[(kk + lh) * SB + b * 32];
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            la.store(As(cur ^ 1), i0);
+            lb.store(Bs(cur ^ 1), j0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA — col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int b = 0; b < NI; ++b) {
+        const int j = j0 + wn * (BN / WN) + b * 32 + l31;
+        if (j >= N) continue;
+        int64_t joff;
+        if (dc.mode == 1) {
+            uint32_t n = dc.dHW.div((uint32_t)j);
+            joff = (int64_t)n * dc.C * dc.HW + (j - n * dc.HW);
+        } else {
+            joff = (int64_t)z * dc.sz + (int64_t)j * dc.sj;
+        }
+        const float bj = (dc.bias && dc.bias_mode == 2) ? dc.bias[j] : 0.f;
+#pragma unroll
+        for (int a = 0; a < MI; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wm * (BM / WM) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (i >= M) continue;
+                float val = acc[a][b][r] + bj;
+                if (dc.bias && dc.bias_mode == 1) val += dc.bias[i];
+                float* dst = dc.p + joff + (dc.mode == 1 ? (int64_t)i * dc.HW : (int64_t)i * dc.si);
+                if (dc.accumulate) val += *dst;
+                *dst = val;
+            }
+        }
+    }
+}
+
+// deterministic split-K combine: out[e] (+)= sum_z slab[z][e], fixed order
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int splits,
+                                     int accumulate);
+
+template <class LA, class LB, int BM, int BN, int BK, int WM, int WN>
+static inline void launch_gemm(const typename LA::Desc& da, const typename LB::Desc& db, const OutDesc& dc, int M,
+                               int N, int K, int splits, hipStream_t st) {
+    int mt = cdiv(M, BM), nt = cdiv(N, BN);
+    int kchunk = cdiv(cdiv(K, splits), BK) * BK;
+    dim3 grid(mt * nt, 1, splits);
+    hipLaunchKernelGGL((gemm_kernel<LA, LB, BM, BN, BK, WM, WN>), grid, dim3(NT), 0, st, da, db, dc, M, N, K, kchunk);
+}
+
+}  // namespace scat

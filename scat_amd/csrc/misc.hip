@@ -1,0 +1,409 @@
+// Element-wise passes, token glue, the iterative regressor head, the train.py loss and Adam.
+// All HBM-bound (or tiny): grid-stride, 16-B accesses where alignment allows.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace scat {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline int grid_for(int64_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+#define GRID_STRIDE(e, n) \
+    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < (n); e += gridDim.x * 256ll)
+
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    GRID_STRIDE(e, n) {
+        float v = x[e];
+        y[e] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    }
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                int64_t n) {
+    GRID_STRIDE(e, n) {
+        float v = x[e];
+        float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+        float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+        dx[e] = dy[e] * (cdf + v * pdf);
+    }
+}
+__global__ void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    GRID_STRIDE(e, n) y[e] = fmaxf(x[e], 0.f);
+}
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                int64_t n) {
+    GRID_STRIDE(e, n) dx[e] = y[e] > 0.f ? dy[e] : 0.f;
+}
+__global__ void axpy_kernel(const float* __restrict__ a, const float* __restrict__ b, float alpha,
+                            float* __restrict__ y, int64_t n) {
+    GRID_STRIDE(e, n) y[e] = a[e] + alpha * b[e];
+}
+
+__global__ void tokens_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                  const float* __restrict__ mask_token, const int32_t* __restrict__ masked,
+                                  int nmasked, float* __restrict__ y, int64_t total, int T, int D) {
+    GRID_STRIDE(e, total) {
+        int d = e % D;
+        int t = (e / D) % T;
+        bool m = false;
+        for (int k = 0; k < nmasked; ++k) m |= (masked[k] == t);
+        y[e] = m ? mask_token[d] : x[e] + (pe ? pe[t * D + d] : 0.f);
+    }
+}
+// dx = dy outside masked rows, 0 inside; dmask_token[d] = sum over batch and masked rows (fixed order)
+__global__ void tokens_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ masked, int nmasked,
+                                  float* __restrict__ dx, int64_t total, int T, int D) {
+    GRID_STRIDE(e, total) {
+        int t = (e / D) % T;
+        bool m = false;
+        for (int k = 0; k < nmasked; ++k) m |= (masked[k] == t);
+        dx[e] = m ? 0.f : dy[e];
+    }
+}
+__global__ void tokens_dmask_kernel(const float* __restrict__ dy, const int32_t* __restrict__ masked, int nmasked,
+                                    float* __restrict__ dmask, int B, int T, int D) {
+    int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < nmasked; ++k) s += dy[((int64_t)b * T + masked[k]) * D + d];
+    dmask[d] = s;
+}
+
+// ---------------------------------------------------------------- regressor head
+// One workgroup per sample.  base_j = bias_j + W[j,:F]·feat is loop invariant.
+
+__global__ __launch_bounds__(256) void regressor_fwd_kernel(const float* __restrict__ feat,
+                                                            const float* __restrict__ feat_out,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ preds,
+                                                            float* __restrict__ out, int B, int F, int P, int iters) {
+    __shared__ float base[128], pred[128], upd[128];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ldw = F + P;
+    const float* fb = feat + (int64_t)b * F;
+    for (int j = wave; j < P; j += 4) {
+        float s = 0.f;
+        for (int f = lane; f < F; f += 64) s = fmaf(w[(int64_t)j * ldw + f], fb[f], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) base[j] = s + bias[j];
+    }
+    if (tid < P) {
+        float v = mean[tid];
+        if (tid >= 3) v += feat_out[(int64_t)b * (P - 3) + tid - 3];
+        pred[tid] = v;
+        preds[((int64_t)0 * B + b) * P + tid] = v;
+    }
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        if (tid < P) {
+            float s = base[tid];
+            for (int p = 0; p < P; ++p) s = fmaf(w[(int64_t)tid * ldw + F + p], pred[p], s);
+            upd[tid] = s;
+        }
+        __syncthreads();
+        if (tid < P) {
+            pred[tid] += upd[tid];
+            preds[((int64_t)(it + 1) * B + b) * P + tid] = pred[tid];
+        }
+        __syncthreads();
+    }
+    if (tid < P) {
+        float v = pred[tid];
+        if (tid >= 3) v -= pred[3 + 3 + (tid - 3) % 3];   // root joint 1 (hand_net.py:389-391)
+        out[(int64_t)b * P + tid] = v;
+    }
+}
+
+// per sample: deltas[t][b][:] = grad wrt the t-th linear output, dsum[b][:] = sum_t, dfeat_out
+__global__ __launch_bounds__(128) void regressor_bwd_delta_kernel(const float* __restrict__ dout,
+                                                                  const float* __restrict__ w,
+                                                                  float* __restrict__ deltas,
+                                                                  float* __restrict__ dsum,
+                                                                  float* __restrict__ dfeat_out, int B, int F, int P,
+                                                                  int iters) {
+    __shared__ float g[128], gn[128];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ldw = F + P;
+    if (tid < P) g[tid] = dout[(int64_t)b * P + tid];
+    __syncthreads();
+    // root-relative backward: joint 1 receives minus the sum over joints, per coordinate
+    float adj = 0.f;
+    if (tid >= 6 && tid < 9) {
+        for (int k = 0; k < (P - 3) / 3; ++k) adj += g[3 + 3 * k + (tid - 6)];
+    }
+    __syncthreads();
+    if (tid >= 6 && tid < 9) g[tid] -= adj;
+    __syncthreads();
+    float ds = 0.f;
+    for (int it = iters - 1; it >= 0; --it) {
+        if (tid < P) {
+            float d = g[tid];   // delta_t = g_{t+1}
+            deltas[((int64_t)it * B + b) * P + tid] = d;
+            ds += d;
+            float s = d;
+            for (int j = 0; j < P; ++j) s = fmaf(g[j], w[(int64_t)j * ldw + F + tid], s);   // g_t = g + W2^T g
+            gn[tid] = s;
+        }
+        __syncthreads();
+        if (tid < P) g[tid] = gn[tid];
+        __syncthreads();
+    }
+    if (tid < P) {
+        dsum[(int64_t)b * P + tid] = ds;
+        if (tid >= 3) dfeat_out[(int64_t)b * (P - 3) + tid - 3] = g[tid];
+    }
+}
+
+// dW[j][c], dbias[j]: thread per (j, c); fixed summation order over (t, b)
+__global__ __launch_bounds__(256) void regressor_bwd_w_kernel(const float* __restrict__ feat,
+                                                              const float* __restrict__ preds,
+                                                              const float* __restrict__ deltas,
+                                                              const float* __restrict__ dsum, float* __restrict__ dw,
+                                                              float* __restrict__ dbias, int B, int F, int P,
+                                                              int iters) {
+    const int ldw = F + P;
+    int64_t e = blockIdx.x * 256ll + threadIdx.x;
+    if (e >= (int64_t)P * ldw) return;
+    int j = e / ldw, c = e % ldw;
+    float s = 0.f;
+    if (c < F) {
+        for (int b = 0; b < B; ++b) s = fmaf(dsum[(int64_t)b * P + j], feat[(int64_t)b * F + c], s);
+    } else {
+        int p = c - F;
+        for (int t = 0; t < iters; ++t)
+            for (int b = 0; b < B; ++b)
+                s = fmaf(deltas[((int64_t)t * B + b) * P + j], preds[((int64_t)t * B + b) * P + p], s);
+    }
+    dw[e] = s;
+    if (c == 0) {
+        float sb = 0.f;
+        for (int b = 0; b < B; ++b) sb += dsum[(int64_t)b * P + j];
+        dbias[j] = sb;
+    }
+}
+
+__global__ __launch_bounds__(256) void regressor_bwd_feat_kernel(const float* __restrict__ dsum,
+                                                                 const float* __restrict__ w,
+                                                                 float* __restrict__ dfeat, int B, int F, int P) {
+    const int ldw = F + P;
+    int64_t e = blockIdx.x * 256ll + threadIdx.x;
+    if (e >= (int64_t)B * F) return;
+    int b = e / F, f = e % F;
+    float s = 0.f;
+    for (int j = 0; j < P; ++j) s = fmaf(dsum[(int64_t)b * P + j], w[(int64_t)j * ldw + f], s);
+    dfeat[e] = s;
+}
+
+// ---------------------------------------------------------------- loss (train.py:165-203)
+
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, const float* __restrict__ gt3d,
+                                                   const float* __restrict__ gt2d, int ld_gt, float w3d, float w2d,
+                                                   float* __restrict__ losses, float* __restrict__ dout, int B) {
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x;
+    double s3 = 0, s2 = 0;
+    const float i3 = 1.0f / (B * 63.0f), i2 = 1.0f / (B * 42.0f);
+    for (int b = tid; b < B; b += 256) {
+        const float* o = out + (int64_t)b * 66;
+        float* d = dout + (int64_t)b * 66;
+        const float c0 = o[0], c1 = o[1], c2 = o[2];
+        float dc0 = 0.f, dc1 = 0.f, dc2 = 0.f;
+        for (int k = 0; k < 21; ++k) {
+            float dj[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float diff = o[3 + 3 * k + c] - gt3d[(int64_t)b * ld_gt + 3 * k + c];
+                s3 += (double)diff * diff;
+                dj[c] = w3d * 2.0f * diff * i3;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float xt = o[3 + 3 * k + c] + (c == 0 ? c1 : c2);
+                float j2 = (c0 * xt) * 112.0f + 112.0f;
+                float diff = j2 - gt2d[(int64_t)b * ld_gt + 2 * k + c];
+                s2 += fabs((double)diff);
+                float g = w2d * i2 * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * 112.0f;
+                dc0 += g * xt;
+                if (c == 0) dc1 += g * c0; else dc2 += g * c0;
+                dj[c] += g * c0;
+            }
+            d[3 + 3 * k + 0] = dj[0];
+            d[3 + 3 * k + 1] = dj[1];
+            d[3 + 3 * k + 2] = dj[2];
+        }
+        d[0] = dc0; d[1] = dc1; d[2] = dc2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s3 += __shfl_down(s3, o, 64); s2 += __shfl_down(s2, o, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s3; red[1][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        double l3 = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (B * 63.0);
+        double l2 = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (B * 42.0);
+        losses[0] = (float)(w3d * l3 + w2d * l2);
+        losses[1] = (float)l3;
+        losses[2] = (float)l2;
+    }
+}
+
+// ---------------------------------------------------------------- Adam
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float bc1, float rsbc2,
+                                                   float gscale) {
+    GRID_STRIDE(e, n) {
+        float gr = g[e] * gscale;
+        float mm = b1 * m[e] + (1.f - b1) * gr;
+        float vv = b2 * v[e] + (1.f - b2) * gr * gr;
+        m[e] = mm;
+        v[e] = vv;
+        float denom = sqrtf(vv) * rsbc2 + eps;
+        p[e] -= (lr / bc1) * (mm / denom);
+    }
+}
+
+}  // namespace scat
+
+using namespace scat;
+
+extern "C" int scat_version(void) { return 100; }
+extern "C" const char* scat_last_error(void) { return g_err; }
+
+extern "C" int scat_check_device(void) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        set_error("scat_check_device: no HIP device");
+        return SCAT_E_ARCH;
+    }
+    SCAT_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, SCAT_E_ARCH, "scat_check_device: %s is not gfx950",
+                 prop.gcnArchName);
+    return SCAT_OK;
+}
+
+#define EW_ENTRY(name, kernel, ...)                                                                 \
+    SCAT_REQUIRE(n >= 0, SCAT_E_SHAPE, #name ": negative size");                                    \
+    if (n == 0) return SCAT_OK;                                                                     \
+    hipLaunchKernelGGL(kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);  \
+    SCAT_LAUNCH_CHECK(#name);                                                                       \
+    return SCAT_OK;
+
+extern "C" int scat_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    SCAT_REQUIRE(x && y, SCAT_E_ARG, "scat_gelu_fwd: null pointer");
+    EW_ENTRY(scat_gelu_fwd, gelu_fwd_kernel, x, y, n)
+}
+extern "C" int scat_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
+    SCAT_REQUIRE(dy && x && dx, SCAT_E_ARG, "scat_gelu_bwd: null pointer");
+    EW_ENTRY(scat_gelu_bwd, gelu_bwd_kernel, dy, x, dx, n)
+}
+extern "C" int scat_relu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    SCAT_REQUIRE(x && y, SCAT_E_ARG, "scat_relu_fwd: null pointer");
+    EW_ENTRY(scat_relu_fwd, relu_fwd_kernel, x, y, n)
+}
+extern "C" int scat_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    SCAT_REQUIRE(dy && y && dx, SCAT_E_ARG, "scat_relu_bwd: null pointer");
+    EW_ENTRY(scat_relu_bwd, relu_bwd_kernel, dy, y, dx, n)
+}
+extern "C" int scat_axpy(const float* a, const float* b, float alpha, float* y, int64_t n, void* stream) {
+    SCAT_REQUIRE(a && b && y, SCAT_E_ARG, "scat_axpy: null pointer");
+    EW_ENTRY(scat_axpy, axpy_kernel, a, b, alpha, y, n)
+}
+
+extern "C" int scat_tokens_fwd(const float* x, const float* pe, const float* mask_token, const int32_t* masked,
+                               int nmasked, float* y, int B, int T, int D, void* stream) {
+    SCAT_REQUIRE(x && y && B > 0 && T > 0 && D > 0, SCAT_E_ARG, "scat_tokens_fwd: bad argument");
+    SCAT_REQUIRE(nmasked == 0 || (masked && mask_token), SCAT_E_ARG, "scat_tokens_fwd: mask arguments");
+    int64_t n = (int64_t)B * T * D;
+    hipLaunchKernelGGL(tokens_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, pe, mask_token,
+                       masked, nmasked, y, n, T, D);
+    SCAT_LAUNCH_CHECK("scat_tokens_fwd");
+    return SCAT_OK;
+}
+
+extern "C" int scat_tokens_bwd(const float* dy, const int32_t* masked, int nmasked, float* dx, float* dmask_token,
+                               int B, int T, int D, void* stream) {
+    SCAT_REQUIRE(dy && dx && B > 0 && T > 0 && D > 0, SCAT_E_ARG, "scat_tokens_bwd: bad argument");
+    SCAT_REQUIRE(nmasked == 0 || masked, SCAT_E_ARG, "scat_tokens_bwd: mask arguments");
+    int64_t n = (int64_t)B * T * D;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tokens_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, dy, masked, nmasked, dx, n, T, D);
+    if (dmask_token)
+        hipLaunchKernelGGL(tokens_dmask_kernel, dim3(cdiv(D, 128)), dim3(128), 0, st, dy, masked, nmasked, dmask_token,
+                           B, T, D);
+    SCAT_LAUNCH_CHECK("scat_tokens_bwd");
+    return SCAT_OK;
+}
+
+extern "C" int scat_regressor_fwd(const float* feat, const float* feat_out, const float* mean, const float* w,
+                                  const float* bias, float* preds, float* out, int B, int F, int P, int iters,
+                                  void* stream) {
+    SCAT_REQUIRE(feat && feat_out && mean && w && bias && preds && out, SCAT_E_ARG, "scat_regressor_fwd: null pointer");
+    SCAT_REQUIRE(B > 0 && F > 0 && P == 66 && iters >= 0, SCAT_E_SHAPE, "scat_regressor_fwd: need P == 66");
+    hipLaunchKernelGGL(regressor_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, feat, feat_out, mean, w, bias,
+                       preds, out, B, F, P, iters);
+    SCAT_LAUNCH_CHECK("scat_regressor_fwd");
+    return SCAT_OK;
+}
+
+extern "C" int64_t scat_regressor_bwd_ws(int B, int F, int P, int iters) {
+    return (int64_t)((int64_t)(iters > 0 ? iters : 1) * B * P + (int64_t)B * P) * sizeof(float);
+}
+
+extern "C" int scat_regressor_bwd(const float* dout, const float* feat, const float* preds, const float* w,
+                                  float* dfeat, float* dfeat_out, float* dw, float* dbias, int B, int F, int P,
+                                  int iters, void* ws, int64_t ws_bytes, void* stream) {
+    SCAT_REQUIRE(dout && feat && preds && w && dfeat && dfeat_out && dw && dbias, SCAT_E_ARG,
+                 "scat_regressor_bwd: null pointer");
+    SCAT_REQUIRE(B > 0 && F > 0 && P == 66 && iters >= 0, SCAT_E_SHAPE, "scat_regressor_bwd: need P == 66");
+    SCAT_REQUIRE(ws && ws_bytes >= scat_regressor_bwd_ws(B, F, P, iters), SCAT_E_WORKSPACE,
+                 "scat_regressor_bwd: workspace too small");
+    float* deltas = (float*)ws;
+    float* dsum = deltas + (int64_t)(iters > 0 ? iters : 1) * B * P;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(regressor_bwd_delta_kernel, dim3(B), dim3(128), 0, st, dout, w, deltas, dsum, dfeat_out, B, F,
+                       P, iters);
+    int64_t nw = (int64_t)P * (F + P);
+    hipLaunchKernelGGL(regressor_bwd_w_kernel, dim3((int)((nw + 255) / 256)), dim3(256), 0, st, feat, preds,
+                       (const float*)deltas, (const float*)dsum, dw, dbias, B, F, P, iters);
+    int64_t nf = (int64_t)B * F;
+    hipLaunchKernelGGL(regressor_bwd_feat_kernel, dim3((int)((nf + 255) / 256)), dim3(256), 0, st,
+                       (const float*)dsum, w, dfeat, B, F, P);
+    SCAT_LAUNCH_CHECK("scat_regressor_bwd");
+    return SCAT_OK;
+}
+
+extern "C" int scat_loss_fwd_bwd(const float* out, const float* gt3d, const float* gt2d, int ld_gt, float w3d,
+                                 float w2d, float* losses, float* dout, int B, void* stream) {
+    SCAT_REQUIRE(out && gt3d && gt2d && losses && dout && B > 0 && ld_gt > 0, SCAT_E_ARG,
+                 "scat_loss_fwd_bwd: bad argument");
+    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, gt3d, gt2d, ld_gt, w3d, w2d,
+                       losses, dout, B);
+    SCAT_LAUNCH_CHECK("scat_loss_fwd_bwd");
+    return SCAT_OK;
+}
+
+extern "C" int scat_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                         float eps, int step, float grad_scale, void* stream) {
+    SCAT_REQUIRE(p && g && m && v, SCAT_E_ARG, "scat_adam: null pointer");
+    SCAT_REQUIRE(n >= 0 && step >= 1, SCAT_E_SHAPE, "scat_adam: bad size/step");
+    if (n == 0) return SCAT_OK;
+    double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                       beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+    SCAT_LAUNCH_CHECK("scat_adam");
+    return SCAT_OK;
+}

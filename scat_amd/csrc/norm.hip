@@ -1,0 +1,402 @@
+// BatchNorm2d (train/eval) and LayerNorm, forward + backward, NCHW fp32.
+// HBM-bound passes: 16-B loads where HW % 4 == 0, per-channel sums accumulated in fp64 in a
+// fixed order (two-stage, no atomics) so results are bitwise reproducible run to run.
+// Reference: nn.BatchNorm2d at models/resnet.py:68-73,108,131; nn.LayerNorm at
+// models/vision_transformer.py:20-26.
+#include "common.h"
+
+namespace scat {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum of two doubles (256 threads); result valid in thread 0
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sh[w] = a; sh[4 + w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = sh[0] + sh[1] + sh[2] + sh[3];
+        b = sh[4] + sh[5] + sh[6] + sh[7];
+    }
+}
+
+static int bn_splits(int B, int C) {
+    int s = cdiv(2048, C);
+    if (s > B) s = B;
+    return s < 1 ? 1 : s;
+}
+
+// ---------------------------------------------------------------- BN forward statistics
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int B, int C, int HW, int S,
+                                                       double* __restrict__ part) {
+    const int c = blockIdx.x, s = blockIdx.y;
+    double s1 = 0, s2 = 0;
+    for (int n = s; n < B; n += S) {
+        const float* p = x + ((int64_t)n * C + c) * HW;
+        if ((HW & 3) == 0) {
+            const float4* p4 = (const float4*)p;
+            for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+                float4 v = p4[i];
+                s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                double v = p[i];
+                s1 += v;
+                s2 += v * v;
+            }
+        }
+    }
+    __shared__ double sh[8];
+    block_sum2(s1, s2, sh);
+    if (threadIdx.x == 0) {
+        part[((int64_t)c * S + s) * 2 + 0] = s1;
+        part[((int64_t)c * S + s) * 2 + 1] = s2;
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ part, int C, int S, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int s = 0; s < S; ++s) {
+        s1 += part[((int64_t)c * S + s) * 2];
+        s2 += part[((int64_t)c * S + s) * 2 + 1];
+    }
+    double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0) var = 0;
+    double invstd = 1.0 / sqrt(var + (double)eps);
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)invstd;
+    float sc = gamma[c] * (float)invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    if (rmean) {
+        double unb = count > 1 ? var * count / (count - 1) : var;
+        rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
+        rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+    }
+}
+
+__global__ void bn_eval_fold_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                    float eps, int C, float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float invstd = 1.0f / sqrtf(rvar[c] + eps);
+    float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+// ---------------------------------------------------------------- BN apply
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       const float* __restrict__ res, int relu,
+                                                       float* __restrict__ y, int64_t rows, int C, int HW) {
+    // one (n,c) row per blockIdx.x step: the channel is block-uniform
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int c = (int)(row % C);
+        const float sc = scale[c], sh = shift[c];
+        const int64_t off = row * HW;
+        if (VEC) {
+            const float4* x4 = (const float4*)(x + off);
+            const float4* r4 = res ? (const float4*)(res + off) : nullptr;
+            float4* y4 = (float4*)(y + off);
+            for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+                float4 v = x4[i];
+                v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+                if (r4) { float4 r = r4[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                y4[i] = v;
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                float v = fmaf(x[off + i], sc, sh);
+                if (res) v += res[off + i];
+                if (relu) v = fmaxf(v, 0.f);
+                y[off + i] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- BN backward
+
+__device__ __forceinline__ float bn_mask(float dy, float x, float yv, bool has_y, int relu, float sc, float sh) {
+    if (has_y) return yv > 0.f ? dy : 0.f;
+    if (relu) return fmaf(x, sc, sh) > 0.f ? dy : 0.f;
+    return dy;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ yout, int relu,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int B, int C, int HW,
+                                                            int S, double* __restrict__ part) {
+    const int c = blockIdx.x, s = blockIdx.y;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    double s1 = 0, s2 = 0;
+    for (int n = s; n < B; n += S) {
+        const int64_t off = ((int64_t)n * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            float xv = x[off + i];
+            float g = bn_mask(dy[off + i], xv, yout ? yout[off + i] : 0.f, yout != nullptr, relu, sc, sh);
+            s1 += g;
+            s2 += (double)g * ((xv - mu) * is);
+        }
+    }
+    __shared__ double shm[8];
+    block_sum2(s1, s2, shm);
+    if (threadIdx.x == 0) {
+        part[((int64_t)c * S + s) * 2 + 0] = s1;
+        part[((int64_t)c * S + s) * 2 + 1] = s2;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, int S, double count,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int s = 0; s < S; ++s) {
+        s1 += part[((int64_t)c * S + s) * 2];
+        s2 += part[((int64_t)c * S + s) * 2 + 1];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    coef[2 * c] = (float)(s1 / count);
+    coef[2 * c + 1] = (float)(s2 / count);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ yout, int relu,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ coef, float* __restrict__ dx,
+                                                           float* __restrict__ dres, int dres_acc, int64_t rows,
+                                                           int C, int HW) {
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int c = (int)(row % C);
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        const float k1 = coef[2 * c], k2 = coef[2 * c + 1], gi = gamma[c] * is;
+        const int64_t off = row * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            float xv = x[off + i];
+            float g = bn_mask(dy[off + i], xv, yout ? yout[off + i] : 0.f, yout != nullptr, relu, sc, sh);
+            float xh = (xv - mu) * is;
+            dx[off + i] = gi * (g - k1 - xh * k2);
+            if (dres) dres[off + i] = dres_acc ? dres[off + i] + g : g;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     int dim, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * dim;
+    float s = 0.f;
+    for (int i = lane; i < dim; i += 64) s += xr[i];
+    const float mu = wave_sum_f(s) / dim;
+    float q = 0.f;
+    for (int i = lane; i < dim; i += 64) { float d = xr[i] - mu; q += d * d; }
+    const float rs = 1.0f / sqrtf(wave_sum_f(q) / dim + eps);
+    float* yr = y + (int64_t)row * dim;
+    for (int i = lane; i < dim; i += 64) yr[i] = (xr[i] - mu) * rs * gamma[i] + beta[i];
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx per row; t = dy * xhat written for the dgamma column sum
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                                     float* __restrict__ t, int rows, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t off = (int64_t)row * dim;
+    const float mu = mean[row], rs = rstd[row];
+    float a = 0.f, b = 0.f;
+    for (int i = lane; i < dim; i += 64) {
+        float g = dy[off + i] * gamma[i], xh = (x[off + i] - mu) * rs;
+        a += g;
+        b += g * xh;
+    }
+    a = wave_sum_f(a) / dim;
+    b = wave_sum_f(b) / dim;
+    for (int i = lane; i < dim; i += 64) {
+        float d = dy[off + i], xh = (x[off + i] - mu) * rs;
+        dx[off + i] = rs * (d * gamma[i] - a - xh * b);
+        t[off + i] = d * xh;
+    }
+}
+
+// out[j] (+)= sum_i x[i*cols + j]; block = 64 columns x 16 row lanes, fixed order
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows,
+                                                      int cols, int accumulate) {
+    __shared__ float sh[16][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (j < cols)
+        for (int i = ty; i < rows; i += 16) s += x[(int64_t)i * cols + j];
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && j < cols) {
+        float r = accumulate ? out[j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += sh[k][tx];
+        out[j] = r;
+    }
+}
+
+}  // namespace scat
+
+using namespace scat;
+
+extern "C" int64_t scat_bn_ws(int B, int C, int HW) {
+    if (B <= 0 || C <= 0) return 0;
+    return (int64_t)C * bn_splits(B, C) * 2 * sizeof(double) + (int64_t)C * 2 * sizeof(float);
+}
+
+extern "C" int scat_bn_train_stats(const float* x, int B, int C, int HW, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps,
+                                   float* save_mean, float* save_invstd, float* scale, float* shift, void* ws,
+                                   int64_t ws_bytes, void* stream) {
+    SCAT_REQUIRE(x && gamma && beta && save_mean && save_invstd && scale && shift, SCAT_E_ARG,
+                 "scat_bn_train_stats: null pointer");
+    SCAT_REQUIRE(B > 0 && C > 0 && HW > 0, SCAT_E_SHAPE, "scat_bn_train_stats: non-positive dimension");
+    SCAT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), SCAT_E_ARG, "scat_bn_train_stats: running pair");
+    SCAT_REQUIRE(ws && ws_bytes >= scat_bn_ws(B, C, HW), SCAT_E_WORKSPACE, "scat_bn_train_stats: workspace too small");
+    const int S = bn_splits(B, C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(256), 0, st, x, B, C, HW, S, (double*)ws);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, C, S,
+                       (double)B * HW, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                       scale, shift);
+    SCAT_LAUNCH_CHECK("scat_bn_train_stats");
+    return SCAT_OK;
+}
+
+extern "C" int scat_bn_eval_fold(const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, int C, float* scale, float* shift,
+                                 void* stream) {
+    SCAT_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, SCAT_E_ARG,
+                 "scat_bn_eval_fold: bad argument");
+    hipLaunchKernelGGL(bn_eval_fold_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, C, scale, shift);
+    SCAT_LAUNCH_CHECK("scat_bn_eval_fold");
+    return SCAT_OK;
+}
+
+extern "C" int scat_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, int relu,
+                             float* y, int B, int C, int HW, void* stream) {
+    SCAT_REQUIRE(x && scale && shift && y, SCAT_E_ARG, "scat_bn_apply: null pointer");
+    SCAT_REQUIRE(B > 0 && C > 0 && HW > 0, SCAT_E_SHAPE, "scat_bn_apply: non-positive dimension");
+    const int64_t rows = (int64_t)B * C;
+    const int blocks = (int)(rows < 8192 ? rows : 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if ((HW & 3) == 0)
+        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(blocks), dim3(256), 0, st, x, scale, shift, residual, relu, y,
+                           rows, C, HW);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(blocks), dim3(256), 0, st, x, scale, shift, residual, relu, y,
+                           rows, C, HW);
+    SCAT_LAUNCH_CHECK("scat_bn_apply");
+    return SCAT_OK;
+}
+
+extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, int relu, const float* scale,
+                           const float* shift, const float* save_mean, const float* save_invstd, const float* gamma,
+                           float* dgamma, float* dbeta, float* dx, float* dres, int dres_accumulate, int B, int C,
+                           int HW, void* ws, int64_t ws_bytes, void* stream) {
+    SCAT_REQUIRE(dy && x && scale && shift && save_mean && save_invstd && gamma && dgamma && dbeta && dx, SCAT_E_ARG,
+                 "scat_bn_bwd: null pointer");
+    SCAT_REQUIRE(B > 0 && C > 0 && HW > 0, SCAT_E_SHAPE, "scat_bn_bwd: non-positive dimension");
+    SCAT_REQUIRE(ws && ws_bytes >= scat_bn_ws(B, C, HW), SCAT_E_WORKSPACE, "scat_bn_bwd: workspace too small");
+    const int S = bn_splits(B, C);
+    double* part = (double*)ws;
+    float* coef = (float*)(part + (int64_t)C * S * 2);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y_out, relu, scale, shift,
+                       save_mean, save_invstd, B, C, HW, S, part);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
+                       (double)B * HW, dgamma, dbeta, coef);
+    const int64_t rows = (int64_t)B * C;
+    const int blocks = (int)(rows < 8192 ? rows : 8192);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dy, x, y_out, relu, scale, shift,
+                       save_mean, save_invstd, gamma, (const float*)coef, dx, dres, dres_accumulate, rows, C, HW);
+    SCAT_LAUNCH_CHECK("scat_bn_bwd");
+    return SCAT_OK;
+}
+
+extern "C" int scat_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                  float* rstd, int rows, int dim, float eps, void* stream) {
+    SCAT_REQUIRE(x && gamma && beta && y && mean && rstd, SCAT_E_ARG, "scat_layernorm_fwd: null pointer");
+    SCAT_REQUIRE(rows > 0 && dim > 0, SCAT_E_SHAPE, "scat_layernorm_fwd: non-positive dimension");
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
+                       rstd, rows, dim, eps);
+    SCAT_LAUNCH_CHECK("scat_layernorm_fwd");
+    return SCAT_OK;
+}
+
+extern "C" int64_t scat_layernorm_bwd_ws(int rows, int dim) {
+    return rows > 0 && dim > 0 ? (int64_t)rows * dim * sizeof(float) : 0;
+}
+
+extern "C" int scat_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                  const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int dim,
+                                  void* ws, int64_t ws_bytes, void* stream) {
+    SCAT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, SCAT_E_ARG,
+                 "scat_layernorm_bwd: null pointer");
+    SCAT_REQUIRE(rows > 0 && dim > 0, SCAT_E_SHAPE, "scat_layernorm_bwd: non-positive dimension");
+    SCAT_REQUIRE(ws && ws_bytes >= scat_layernorm_bwd_ws(rows, dim), SCAT_E_WORKSPACE,
+                 "scat_layernorm_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* t = (float*)ws;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, t, rows,
+                       dim);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim, 64)), dim3(1024), 0, st, (const float*)t, dgamma, rows, dim, 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim, 64)), dim3(1024), 0, st, dy, dbeta, rows, dim, 0);
+    SCAT_LAUNCH_CHECK("scat_layernorm_bwd");
+    return SCAT_OK;
+}
+
+extern "C" int scat_colsum(const float* x, float* out, int rows, int cols, int accumulate, void* stream) {
+    SCAT_REQUIRE(x && out && rows > 0 && cols > 0, SCAT_E_ARG, "scat_colsum: bad argument");
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, (hipStream_t)stream, x, out, rows, cols,
+                       accumulate);
+    SCAT_LAUNCH_CHECK("scat_colsum");
+    return SCAT_OK;
+}

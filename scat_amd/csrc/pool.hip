@@ -1,0 +1,144 @@
+// MaxPool2d(3,2,1) with the stem BatchNorm+ReLU fused into the load, and the 7x7 global
+// average pool.  Reference: models/resnet.py:110,146-147 and :115,155-157.
+#include "common.h"
+
+namespace scat {
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int relu,
+                                                          float* __restrict__ y, int8_t* __restrict__ idx,
+                                                          int64_t total, int C, int H, int W, int OH, int OW) {
+    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+        int ox = e % OW;
+        int64_t r = e / OW;
+        int oy = r % OH;
+        int64_t nc = r / OH;
+        int c = nc % C;
+        const float* p = x + nc * H * W;
+        float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+        float best = -INFINITY;
+        int bi = -1;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            int iy = oy * 2 - 1 + kh;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                int ix = ox * 2 - 1 + kw;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                float v = p[iy * W + ix];
+                if (scale) v = fmaf(v, sc, sh);
+                if (relu) v = fmaxf(v, 0.f);
+                if (v > best || v != v) { best = v; bi = kh * 3 + kw; }   // first maximum wins, like ATen
+            }
+        }
+        y[e] = best;
+        idx[e] = (int8_t)bi;
+    }
+}
+
+// gather form (no atomics): an input pixel sums the windows whose arg-max it is
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
+                                                          const int8_t* __restrict__ idx, float* __restrict__ dx,
+                                                          int64_t total, int H, int W, int OH, int OW) {
+    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+        int ix = e % W;
+        int64_t r = e / W;
+        int iy = r % H;
+        int64_t nc = r / H;
+        const float* g = dy + nc * OH * OW;
+        const int8_t* id = idx + nc * OH * OW;
+        float s = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            int t = iy + 1 - kh;
+            if (t < 0 || (t & 1) || (t >> 1) >= OH) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                int u = ix + 1 - kw;
+                if (u < 0 || (u & 1) || (u >> 1) >= OW) continue;
+                int o = (t >> 1) * OW + (u >> 1);
+                if (id[o] == kh * 3 + kw) s += g[o];
+            }
+        }
+        dx[e] = s;
+    }
+}
+
+// 16 lanes per (n,c) row
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          int64_t rows, int HW, int relu) {
+    int64_t row = blockIdx.x * 16ll + (threadIdx.x >> 4);
+    int l = threadIdx.x & 15;
+    float s = 0.f;
+    if (row < rows)
+        for (int i = l; i < HW; i += 16) s += x[row * HW + i];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+    if (row < rows && l == 0) {
+        s /= HW;
+        y[row] = relu ? fmaxf(s, 0.f) : s;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          int relu, float* __restrict__ dx, int64_t total, int HW,
+                                                          int accumulate) {
+    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+        int64_t row = e / HW;
+        float g = dy[row] / HW;
+        if (relu && !(y[row] > 0.f)) g = 0.f;
+        dx[e] = accumulate ? dx[e] + g : g;
+    }
+}
+
+static inline int grid_for(int64_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+}  // namespace scat
+
+using namespace scat;
+
+extern "C" int scat_maxpool3x3s2_fwd(const float* x, const float* scale, const float* shift, int relu, float* y,
+                                     int8_t* idx, int B, int C, int H, int W, void* stream) {
+    SCAT_REQUIRE(x && y && idx, SCAT_E_ARG, "scat_maxpool3x3s2_fwd: null pointer");
+    SCAT_REQUIRE((scale == nullptr) == (shift == nullptr), SCAT_E_ARG, "scat_maxpool3x3s2_fwd: scale/shift pair");
+    SCAT_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, SCAT_E_SHAPE, "scat_maxpool3x3s2_fwd: non-positive dimension");
+    int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    int64_t total = (int64_t)B * C * OH * OW;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                       relu, y, idx, total, C, H, W, OH, OW);
+    SCAT_LAUNCH_CHECK("scat_maxpool3x3s2_fwd");
+    return SCAT_OK;
+}
+
+extern "C" int scat_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* dx, int B, int C, int H, int W,
+                                     void* stream) {
+    SCAT_REQUIRE(dy && idx && dx, SCAT_E_ARG, "scat_maxpool3x3s2_bwd: null pointer");
+    SCAT_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, SCAT_E_SHAPE, "scat_maxpool3x3s2_bwd: non-positive dimension");
+    int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    int64_t total = (int64_t)B * C * H * W;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx,
+                       total, H, W, OH, OW);
+    SCAT_LAUNCH_CHECK("scat_maxpool3x3s2_bwd");
+    return SCAT_OK;
+}
+
+extern "C" int scat_avgpool_fwd(const float* x, float* y, int B, int C, int HW, int relu, void* stream) {
+    SCAT_REQUIRE(x && y && B > 0 && C > 0 && HW > 0, SCAT_E_ARG, "scat_avgpool_fwd: bad argument");
+    int64_t rows = (int64_t)B * C;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((int)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       rows, HW, relu);
+    SCAT_LAUNCH_CHECK("scat_avgpool_fwd");
+    return SCAT_OK;
+}
+
+extern "C" int scat_avgpool_bwd(const float* dy, const float* y, int relu, float* dx, int B, int C, int HW,
+                                int accumulate, void* stream) {
+    SCAT_REQUIRE(dy && y && dx && B > 0 && C > 0 && HW > 0, SCAT_E_ARG, "scat_avgpool_bwd: bad argument");
+    int64_t total = (int64_t)B * C * HW;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, y, relu, dx,
+                       total, HW, accumulate);
+    SCAT_LAUNCH_CHECK("scat_avgpool_bwd");
+    return SCAT_OK;
+}

@@ -1,0 +1,352 @@
+"""Thin tensor-level wrappers over the C ABI (no autograd here).
+
+PyTorch is plumbing only: it owns device memory and the stream. Every function passes
+``tensor.data_ptr()`` + explicit sizes to libscat_hip and returns torch tensors that view
+caller-owned buffers. There is no fallback path: tensors must be fp32, contiguous, on the GPU.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import ScatError, lib
+
+_ws_cache = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ScatError(f"scat_amd op needs contiguous fp32 GPU tensors, got {t.dtype} {t.device} "
+                            f"contiguous={t.is_contiguous()} (no CPU fallback on the product path)")
+
+
+def workspace(nbytes: int, device, slot: str = "default") -> torch.Tensor:
+    """Caller-owned scratch, grown on demand, one buffer per (device, slot). Stream-ordered reuse
+    is safe because every consumer runs on the current stream."""
+    key = (str(device), slot)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ---------------------------------------------------------------- convolution
+
+def conv_out_hw(H, W, k, stride, pad):
+    return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+
+
+def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, bias=None, out=None):
+    _chk(x, w, in_scale, in_shift, bias)
+    B, Cin, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    OH, OW = conv_out_hw(H, W, KH, stride, pad)
+    y = out if out is not None else torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    lib().scat_conv2d_fwd(_p(x), _p(w), _p(bias), _p(y), B, Cin, H, W, Cout, KH, KW, stride, pad,
+                          _p(in_scale), _p(in_shift), int(in_relu), _stream())
+    return y
+
+
+def conv2d_wt(w, out=None):
+    _chk(w)
+    Cout, Cin, KH, KW = w.shape
+    wt = out if out is not None else torch.empty((Cin, Cout * KH * KW), dtype=torch.float32, device=w.device)
+    lib().scat_conv2d_wt(_p(w), _p(wt), Cout, Cin, KH, KW, _stream())
+    return wt
+
+
+def conv2d_dgrad(dy, wt, x_shape, w_shape, stride, pad, out=None, accumulate=False):
+    _chk(dy, wt, out)
+    B, Cin, H, W = x_shape
+    Cout, _, KH, KW = w_shape
+    dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    lib().scat_conv2d_dgrad(_p(dy), _p(wt), _p(dx), B, Cin, H, W, Cout, KH, KW, stride, pad, int(accumulate),
+                            _stream())
+    return dx
+
+
+def conv2d_wgrad(dy, x, w_shape, stride, pad, in_scale=None, in_shift=None, in_relu=False, out=None):
+    _chk(dy, x, in_scale, in_shift, out)
+    B, Cin, H, W = x.shape
+    Cout, _, KH, KW = w_shape
+    dw = out if out is not None else torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    need = lib().scat_conv2d_wgrad_ws(B, Cin, H, W, Cout, KH, KW, stride, pad)
+    ws = workspace(need, x.device)
+    lib().scat_conv2d_wgrad(_p(dy), _p(x), _p(dw), B, Cin, H, W, Cout, KH, KW, stride, pad, _p(in_scale),
+                            _p(in_shift), int(in_relu), _p(ws), ws.numel(), _stream())
+    return dw
+
+
+# ---------------------------------------------------------------- GEMM
+
+def gemm(a, a_si, a_sk, b, b_sk, b_sj, c, c_si, c_sj, M, N, K, bias=None, bias_mode=0, accumulate=False):
+    need = lib().scat_gemm_ws(M, N, K)
+    ws = workspace(need, c.device) if need else None
+    lib().scat_gemm(_p(a), a_si, a_sk, _p(b), b_sk, b_sj, _p(c), c_si, c_sj, M, N, K, _p(bias), bias_mode,
+                    int(accumulate), _p(ws), ws.numel() if ws is not None else 0, _stream())
+    return c
+
+
+def linear_fwd(x2d, w, bias=None, out=None):
+    """y[M,N] = x[M,K] @ w[N,K]^T + bias"""
+    _chk(x2d, w, bias, out)
+    M, K = x2d.shape
+    N = w.shape[0]
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=x2d.device)
+    return gemm(x2d, K, 1, w, 1, K, y, N, 1, M, N, K, bias, 2 if bias is not None else 0)
+
+
+def linear_dgrad(dy2d, w, out=None, accumulate=False):
+    """dx[M,K] = dy[M,N] @ w[N,K]"""
+    _chk(dy2d, w, out)
+    M, N = dy2d.shape
+    K = w.shape[1]
+    dx = out if out is not None else torch.empty((M, K), dtype=torch.float32, device=dy2d.device)
+    return gemm(dy2d, N, 1, w, K, 1, dx, K, 1, M, K, N, accumulate=accumulate)
+
+
+def linear_wgrad(dy2d, x2d, out=None):
+    """dw[N,K] = dy[M,N]^T @ x[M,K]"""
+    _chk(dy2d, x2d, out)
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    dw = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=x2d.device)
+    return gemm(dy2d, 1, N, x2d, K, 1, dw, K, 1, N, K, M)
+
+
+def colsum(x2d, out=None, accumulate=False):
+    _chk(x2d, out)
+    rows, cols = x2d.shape
+    o = out if out is not None else torch.empty((cols,), dtype=torch.float32, device=x2d.device)
+    lib().scat_colsum(_p(x2d), _p(o), rows, cols, int(accumulate), _stream())
+    return o
+
+
+# ---------------------------------------------------------------- BatchNorm
+
+def bn_train_stats(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+    """-> (save_mean, save_invstd, scale, shift); running stats updated in place."""
+    _chk(x, gamma, beta, running_mean, running_var)
+    B, C, H, W = x.shape
+    o = torch.empty((4, C), dtype=torch.float32, device=x.device)
+    ws = workspace(lib().scat_bn_ws(B, C, H * W), x.device)
+    lib().scat_bn_train_stats(_p(x), B, C, H * W, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum,
+                              eps, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(ws), ws.numel(), _stream())
+    return o[0], o[1], o[2], o[3]
+
+
+def bn_eval_fold(gamma, beta, running_mean, running_var, eps=1e-5):
+    _chk(gamma, beta, running_mean, running_var)
+    C = gamma.numel()
+    o = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
+    lib().scat_bn_eval_fold(_p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, C, _p(o[0]), _p(o[1]),
+                            _stream())
+    return o[0], o[1]
+
+
+def bn_apply(x, scale, shift, residual=None, relu=False, out=None):
+    _chk(x, scale, shift, residual, out)
+    B, C, H, W = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    lib().scat_bn_apply(_p(x), _p(scale), _p(shift), _p(residual), int(relu), _p(y), B, C, H * W, _stream())
+    return y
+
+
+def bn_bwd(dy, x, y_out, relu, scale, shift, save_mean, save_invstd, gamma, dgamma=None, dbeta=None, dx=None,
+           dres=None, dres_accumulate=False):
+    """-> (dx, dgamma, dbeta); if dres is given, the masked gradient is written/accumulated there."""
+    _chk(dy, x, y_out, scale, shift, save_mean, save_invstd, gamma, dgamma, dbeta, dx, dres)
+    B, C, H, W = x.shape
+    dx = dx if dx is not None else torch.empty_like(x)
+    dgamma = dgamma if dgamma is not None else torch.empty_like(gamma)
+    dbeta = dbeta if dbeta is not None else torch.empty_like(gamma)
+    ws = workspace(lib().scat_bn_ws(B, C, H * W), x.device)
+    lib().scat_bn_bwd(_p(dy), _p(x), _p(y_out), int(relu), _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
+                      _p(gamma), _p(dgamma), _p(dbeta), _p(dx), _p(dres), int(dres_accumulate), B, C, H * W, _p(ws),
+                      ws.numel(), _stream())
+    return dx, dgamma, dbeta
+
+
+# ---------------------------------------------------------------- pooling
+
+def maxpool_fwd(x, scale=None, shift=None, relu=False):
+    _chk(x, scale, shift)
+    B, C, H, W = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, C, OH, OW), dtype=torch.int8, device=x.device)
+    lib().scat_maxpool3x3s2_fwd(_p(x), _p(scale), _p(shift), int(relu), _p(y), _p(idx), B, C, H, W, _stream())
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, x_shape):
+    _chk(dy)
+    B, C, H, W = x_shape
+    dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    lib().scat_maxpool3x3s2_bwd(_p(dy), _p(idx), _p(dx), B, C, H, W, _stream())
+    return dx
+
+
+def avgpool_fwd(x, relu=True):
+    _chk(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    lib().scat_avgpool_fwd(_p(x), _p(y), B, C, H * W, int(relu), _stream())
+    return y
+
+
+def avgpool_bwd(dy, y, x_shape, relu=True, out=None, accumulate=False):
+    _chk(dy, y, out)
+    B, C, H, W = x_shape
+    dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    lib().scat_avgpool_bwd(_p(dy), _p(y), int(relu), _p(dx), B, C, H * W, int(accumulate), _stream())
+    return dx
+
+
+# ---------------------------------------------------------------- LayerNorm / attention / elementwise
+
+def layernorm_fwd(x2d, gamma, beta, eps=1e-5):
+    _chk(x2d, gamma, beta)
+    rows, dim = x2d.shape
+    y = torch.empty_like(x2d)
+    st = torch.empty((2, rows), dtype=torch.float32, device=x2d.device)
+    lib().scat_layernorm_fwd(_p(x2d), _p(gamma), _p(beta), _p(y), _p(st[0]), _p(st[1]), rows, dim, eps, _stream())
+    return y, st[0], st[1]
+
+
+def layernorm_bwd(dy2d, x2d, gamma, mean, rstd):
+    _chk(dy2d, x2d, gamma, mean, rstd)
+    rows, dim = x2d.shape
+    dx = torch.empty_like(x2d)
+    dg = torch.empty((2, dim), dtype=torch.float32, device=x2d.device)
+    ws = workspace(lib().scat_layernorm_bwd_ws(rows, dim), x2d.device)
+    lib().scat_layernorm_bwd(_p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg[0]), _p(dg[1]), rows,
+                             dim, _p(ws), ws.numel(), _stream())
+    return dx, dg[0], dg[1]
+
+
+def attention_fwd(qkv, heads, dim_head, scale):
+    """qkv[B,n,3*h*d] -> (out[B,n,h*d], attn[B,h,n,n])"""
+    _chk(qkv)
+    B, n, _ = qkv.shape
+    out = torch.empty((B, n, heads * dim_head), dtype=torch.float32, device=qkv.device)
+    attn = torch.empty((B, heads, n, n), dtype=torch.float32, device=qkv.device)
+    lib().scat_attention_fwd(_p(qkv), _p(out), _p(attn), B, n, heads, dim_head, scale, _stream())
+    return out, attn
+
+
+def attention_bwd(dout, qkv, attn, heads, dim_head, scale):
+    _chk(dout, qkv, attn)
+    B, n, _ = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    lib().scat_attention_bwd(_p(dout), _p(qkv), _p(attn), _p(dqkv), B, n, heads, dim_head, scale, _stream())
+    return dqkv
+
+
+def gelu_fwd(x):
+    _chk(x)
+    y = torch.empty_like(x)
+    lib().scat_gelu_fwd(_p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def gelu_bwd(dy, x):
+    _chk(dy, x)
+    dx = torch.empty_like(x)
+    lib().scat_gelu_bwd(_p(dy), _p(x), _p(dx), x.numel(), _stream())
+    return dx
+
+
+def relu_fwd(x):
+    _chk(x)
+    y = torch.empty_like(x)
+    lib().scat_relu_fwd(_p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def relu_bwd(dy, y):
+    _chk(dy, y)
+    dx = torch.empty_like(y)
+    lib().scat_relu_bwd(_p(dy), _p(y), _p(dx), y.numel(), _stream())
+    return dx
+
+
+def axpy(a, b, alpha=1.0, out=None):
+    _chk(a, b, out)
+    y = out if out is not None else torch.empty_like(a)
+    lib().scat_axpy(_p(a), _p(b), float(alpha), _p(y), a.numel(), _stream())
+    return y
+
+
+def tokens_fwd(x, pe, mask_token, masked_idx):
+    """x[B,T,D] + pe[T,D]; rows in masked_idx (int32 GPU tensor or None) <- mask_token[D]."""
+    _chk(x, pe, mask_token)
+    B, T, D = x.shape
+    y = torch.empty_like(x)
+    nm = 0 if masked_idx is None else masked_idx.numel()
+    lib().scat_tokens_fwd(_p(x), _p(pe), _p(mask_token), _p(masked_idx), nm, _p(y), B, T, D, _stream())
+    return y
+
+
+def tokens_bwd(dy, masked_idx, want_dmask=True):
+    _chk(dy)
+    B, T, D = dy.shape
+    dx = torch.empty_like(dy)
+    nm = 0 if masked_idx is None else masked_idx.numel()
+    dm = torch.zeros((D,), dtype=torch.float32, device=dy.device) if want_dmask else None
+    lib().scat_tokens_bwd(_p(dy), _p(masked_idx), nm, _p(dx), _p(dm) if nm else 0, B, T, D, _stream())
+    return dx, dm
+
+
+def regressor_fwd(feat, feat_out, mean, w, bias, iters):
+    _chk(feat, feat_out, mean, w, bias)
+    B, F = feat.shape
+    P = w.shape[0]
+    preds = torch.empty((iters + 1, B, P), dtype=torch.float32, device=feat.device)
+    out = torch.empty((B, P), dtype=torch.float32, device=feat.device)
+    lib().scat_regressor_fwd(_p(feat), _p(feat_out), _p(mean), _p(w), _p(bias), _p(preds), _p(out), B, F, P, iters,
+                             _stream())
+    return out, preds
+
+
+def regressor_bwd(dout, feat, preds, w, iters):
+    _chk(dout, feat, preds, w)
+    B, F = feat.shape
+    P = w.shape[0]
+    dfeat = torch.empty_like(feat)
+    dfeat_out = torch.empty((B, P - 3), dtype=torch.float32, device=feat.device)
+    dw = torch.empty_like(w)
+    dbias = torch.empty((P,), dtype=torch.float32, device=feat.device)
+    ws = workspace(lib().scat_regressor_bwd_ws(B, F, P, iters), feat.device)
+    lib().scat_regressor_bwd(_p(dout), _p(feat), _p(preds), _p(w), _p(dfeat), _p(dfeat_out), _p(dw), _p(dbias), B, F,
+                             P, iters, _p(ws), ws.numel(), _stream())
+    return dfeat, dfeat_out, dw, dbias
+
+
+def loss_fwd_bwd(out, labels, w3d=100000.0, w2d=10.0):
+    """labels[B,105] (or [B,166]) as train.py:188-198 -> (losses[3] = loss,l3d,l2d ; dout[B,66])"""
+    _chk(out, labels)
+    B = out.shape[0]
+    ld = labels.shape[1]
+    o3, o2 = (0, 63) if ld == 105 else (61, 124)
+    losses = torch.empty((3,), dtype=torch.float32, device=out.device)
+    dout = torch.empty_like(out)
+    base = labels.data_ptr()
+    lib().scat_loss_fwd_bwd(_p(out), base + 4 * o3, base + 4 * o2, ld, w3d, w2d, _p(losses), _p(dout), B, _stream())
+    return losses, dout
+
+
+def adam(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _chk(p, g, m, v)
+    lib().scat_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream())

@@ -1,0 +1,280 @@
+"""Per-kernel parity on a real MI355X: every C-ABI op against the plain PyTorch fp32/fp64 CPU op
+it replaces, on seeded inputs. Tolerance (norm-wise relative, max|a-b|/max|b|): 2e-5 for
+contractions (fp32 fma chains in a different order), 1e-5 for element-wise / normalisation."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.util import rel_err
+from scat_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def t(seed, name, shape, std=1.0):
+    return torch.from_numpy(synth.normal_like(seed, name, shape, std))
+
+
+def g(x):
+    return x.to(DEV).contiguous()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from scat_amd import ops as o
+    from scat_amd._lib import lib
+
+    lib().scat_check_device()
+    return o
+
+
+# every distinct conv geometry of the ResNet-50 path + stem + 1x1 reduction
+CONVS = [
+    # Cin, Cout, k, s, p, H
+    (3, 64, 7, 2, 3, 224), (64, 64, 1, 1, 0, 56), (64, 64, 3, 1, 1, 56), (64, 256, 1, 1, 0, 56),
+    (256, 64, 1, 1, 0, 56), (256, 128, 1, 1, 0, 56), (128, 128, 3, 2, 1, 56), (128, 512, 1, 1, 0, 28),
+    (256, 512, 1, 2, 0, 56), (512, 128, 1, 1, 0, 28), (128, 128, 3, 1, 1, 28), (512, 256, 1, 1, 0, 28),
+    (256, 256, 3, 2, 1, 28), (256, 1024, 1, 1, 0, 14), (512, 1024, 1, 2, 0, 28), (1024, 256, 1, 1, 0, 14),
+    (256, 256, 3, 1, 1, 14), (1024, 512, 1, 1, 0, 14), (512, 512, 3, 2, 1, 14), (512, 2048, 1, 1, 0, 7),
+    (1024, 2048, 1, 2, 0, 14), (2048, 512, 1, 1, 0, 7), (512, 512, 3, 1, 1, 7), (512, 21, 1, 1, 0, 28),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,H", CONVS)
+def test_conv_fwd_dgrad_wgrad(ops, cin, cout, k, s, p, H):
+    B = 3 if H <= 56 else 2
+    x = t(1, "x", (B, cin, H, H)).requires_grad_(True)
+    w = t(2, "w", (cout, cin, k, k), std=(2.0 / (cin * k * k)) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x.double(), w.double(), stride=s, padding=p)
+    dy = t(3, "dy", tuple(y.shape))
+    dx_ref, dw_ref = torch.autograd.grad(y, (x, w), dy.double())
+    yg = ops.conv2d_fwd(g(x.detach()), g(w.detach()), s, p)
+    assert rel_err(yg, y) < 2e-5
+    dwg = ops.conv2d_wgrad(g(dy), g(x.detach()), tuple(w.shape), s, p)
+    assert rel_err(dwg, dw_ref) < 2e-5
+    if k != 7:
+        wt = ops.conv2d_wt(g(w.detach()))
+        dxg = ops.conv2d_dgrad(g(dy), wt, tuple(x.shape), tuple(w.shape), s, p)
+        assert rel_err(dxg, dx_ref) < 2e-5
+        # accumulate form
+        base = g(t(4, "acc", tuple(x.shape)))
+        dxa = ops.conv2d_dgrad(g(dy), wt, tuple(x.shape), tuple(w.shape), s, p, out=base.clone(), accumulate=True)
+        assert rel_err(dxa, dx_ref + base.cpu().double()) < 2e-5
+
+
+def test_conv_fused_input_transform(ops):
+    """conv reading relu(x*scale+shift): zero padding must stay zero AFTER the transform."""
+    B, cin, cout, H = 2, 32, 48, 14
+    x = t(5, "x", (B, cin, H, H))
+    w = t(6, "w", (cout, cin, 3, 3), std=0.1)
+    sc = torch.from_numpy(synth.uniform(7, "sc", (cin,), 0.5, 1.5))
+    sh = torch.from_numpy(synth.uniform(8, "sh", (cin,), -0.5, 0.5))
+    a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    for s in (1, 2):
+        y = F.conv2d(a.double(), w.double(), stride=s, padding=1)
+        yg = ops.conv2d_fwd(g(x), g(w), s, 1, g(sc), g(sh), True)
+        assert rel_err(yg, y) < 2e-5
+        dy = t(9, "dy", tuple(y.shape))
+        dw_ref = torch.nn.grad.conv2d_weight(a.double(), tuple(w.shape), dy.double(), stride=s, padding=1)
+        dwg = ops.conv2d_wgrad(g(dy), g(x), tuple(w.shape), s, 1, g(sc), g(sh), True)
+        assert rel_err(dwg, dw_ref) < 2e-5
+
+
+def test_conv_bias_and_edge_batches(ops):
+    for B in (1, 5):
+        x = t(10, "x", (B, 20, 9, 9))
+        w = t(11, "w", (130, 20, 1, 1), std=0.2)
+        b = t(12, "b", (130,))
+        y = F.conv2d(x.double(), w.double(), b.double())
+        assert rel_err(ops.conv2d_fwd(g(x), g(w), 1, 0, bias=g(b)), y) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(2016, 1536, 784), (2016, 784, 512), (84, 588, 784), (84, 3, 147),
+                                   (96, 1024, 2048), (2016, 196, 294), (7, 66, 1090), (300, 200, 100)])
+def test_linear(ops, M, N, K):
+    x = t(13, "x", (M, K)).requires_grad_(True)
+    w = t(14, "w", (N, K), std=K ** -0.5).requires_grad_(True)
+    b = t(15, "b", (N,))
+    y = F.linear(x.double(), w.double(), b.double())
+    dy = t(16, "dy", (M, N))
+    dx_ref, dw_ref = torch.autograd.grad(y, (x, w), dy.double())
+    assert rel_err(ops.linear_fwd(g(x.detach()), g(w.detach()), g(b)), y) < 2e-5
+    assert rel_err(ops.linear_dgrad(g(dy), g(w.detach())), dx_ref) < 2e-5
+    assert rel_err(ops.linear_wgrad(g(dy), g(x.detach())), dw_ref) < 2e-5
+    assert rel_err(ops.colsum(g(dy)), dy.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("B,C,H", [(4, 64, 56), (3, 256, 14), (5, 2048, 7), (2, 64, 112)])
+def test_batchnorm(ops, B, C, H):
+    x = (t(17, "x", (B, C, H, H)) * 1.7 + 0.4).requires_grad_(True)
+    gamma = torch.from_numpy(synth.uniform(18, "g", (C,), 0.5, 1.5)).requires_grad_(True)
+    beta = torch.from_numpy(synth.uniform(19, "b", (C,), -0.3, 0.3)).requires_grad_(True)
+    rm = torch.from_numpy(synth.uniform(20, "rm", (C,), -0.2, 0.2))
+    rv = torch.from_numpy(synth.uniform(21, "rv", (C,), 0.6, 1.4))
+    res = t(22, "res", (B, C, H, H))
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.relu(F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5) + res)
+    dy = t(23, "dy", (B, C, H, H))
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(y, (x, gamma, beta), dy)
+    xg, gg, bg, rmg, rvg = g(x.detach()), g(gamma.detach()), g(beta.detach()), g(rm), g(rv)
+    mean, invstd, scale, shift = ops.bn_train_stats(xg, gg, bg, rmg, rvg)
+    assert rel_err(rmg, rm_ref) < 1e-5 and rel_err(rvg, rv_ref) < 1e-5
+    yg = ops.bn_apply(xg, scale, shift, g(res), relu=True)
+    assert rel_err(yg, y) < 1e-5
+    dres = torch.empty_like(xg)
+    dxg, dgg, dbg = ops.bn_bwd(g(dy), xg, yg, True, scale, shift, mean, invstd, gg, dres=dres)
+    assert rel_err(dxg, dx_ref) < 2e-5 and rel_err(dgg, dg_ref) < 2e-5 and rel_err(dbg, db_ref) < 2e-5
+    assert rel_err(dres, dy * (y > 0)) < 1e-6
+    # recomputed-mask form (no residual): y = relu(bn(x))
+    y2 = F.relu(F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5))
+    dx2, dg2, db2 = torch.autograd.grad(y2, (x, gamma, beta), dy)
+    dxg2, dgg2, dbg2 = ops.bn_bwd(g(dy), xg, None, True, scale, shift, mean, invstd, gg)
+    assert rel_err(dxg2, dx2) < 2e-5 and rel_err(dgg2, dg2) < 2e-5 and rel_err(dbg2, db2) < 2e-5
+    # eval fold
+    sc_e, sh_e = ops.bn_eval_fold(gg, bg, rmg, rvg)
+    ye = F.batch_norm(x.detach(), rm_ref, rv_ref, gamma.detach(), beta.detach(), False, 0.1, 1e-5)
+    assert rel_err(ops.bn_apply(xg, sc_e, sh_e), ye) < 1e-5
+
+
+def test_pools(ops):
+    B, C, H = 3, 16, 112
+    x = t(24, "x", (B, C, H, H)).requires_grad_(True)
+    sc = torch.from_numpy(synth.uniform(25, "sc", (C,), 0.5, 1.5))
+    sh = torch.from_numpy(synth.uniform(26, "sh", (C,), -0.5, 0.5))
+    a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    a.retain_grad()
+    y = F.max_pool2d(a, 3, 2, 1)
+    dy = t(27, "dy", tuple(y.shape))
+    y.backward(dy)
+    yg, idx = ops.maxpool_fwd(g(x.detach()), g(sc), g(sh), True)
+    assert rel_err(yg, y) < 1e-6
+    da = ops.maxpool_bwd(g(dy), idx, tuple(x.shape))
+    # ties at exactly 0 after ReLU are killed by the ReLU mask downstream: compare on a>0
+    m = (a > 0).double()
+    assert rel_err(da.cpu().double() * m, a.grad.double() * m) < 1e-6
+    # odd size, no fused transform
+    x2 = t(28, "x2", (2, 5, 13, 13))
+    y2g, _ = ops.maxpool_fwd(g(x2))
+    assert rel_err(y2g, F.max_pool2d(x2, 3, 2, 1)) == 0.0
+    # avg pool 7x7 + relu
+    x4 = t(29, "x4", (4, 128, 7, 7)).requires_grad_(True)
+    f = F.relu(F.avg_pool2d(x4, 7, 1).flatten(1))
+    df = t(30, "df", (4, 128))
+    f.backward(df)
+    fg = ops.avgpool_fwd(g(x4.detach()))
+    assert rel_err(fg, f) < 1e-6
+    assert rel_err(ops.avgpool_bwd(g(df), fg, tuple(x4.shape)), x4.grad) < 1e-6
+
+
+@pytest.mark.parametrize("rows,dim", [(84, 784), (2016, 392), (40, 196), (7, 50)])
+def test_layernorm(ops, rows, dim):
+    x = (t(31, "x", (rows, dim)) * 2 + 0.3).requires_grad_(True)
+    gm = torch.from_numpy(synth.uniform(32, "g", (dim,), 0.7, 1.3)).requires_grad_(True)
+    bt = torch.from_numpy(synth.uniform(33, "b", (dim,), -0.2, 0.2)).requires_grad_(True)
+    y = F.layer_norm(x, (dim,), gm, bt, 1e-5)
+    dy = t(34, "dy", (rows, dim))
+    dx, dg, db = torch.autograd.grad(y, (x, gm, bt), dy)
+    yg, mean, rstd = ops.layernorm_fwd(g(x.detach()), g(gm.detach()), g(bt.detach()))
+    assert rel_err(yg, y) < 1e-5
+    dxg, dgg, dbg = ops.layernorm_bwd(g(dy), g(x.detach()), g(gm.detach()), mean, rstd)
+    assert rel_err(dxg, dx) < 1e-5 and rel_err(dgg, dg) < 1e-5 and rel_err(dbg, db) < 1e-5
+
+
+@pytest.mark.parametrize("B,n,heads", [(4, 21, 8), (2, 128, 8), (3, 65, 2), (2, 21, 16)])
+def test_attention_core(ops, B, n, heads):
+    d = 64
+    qkv = t(35, "qkv", (B, n, 3 * heads * d)).requires_grad_(True)
+    scale = d ** -0.5
+    q, k, v = (z.reshape(B, n, heads, d).permute(0, 2, 1, 3) for z in qkv.split(heads * d, dim=-1))
+    attn = (q @ k.transpose(-1, -2) * scale).softmax(-1)
+    out = (attn @ v).permute(0, 2, 1, 3).reshape(B, n, heads * d)
+    do = t(36, "do", (B, n, heads * d))
+    (dqkv,) = torch.autograd.grad(out, qkv, do)
+    og, ag = ops.attention_fwd(g(qkv.detach()), heads, d, scale)
+    assert rel_err(og, out) < 1e-5 and rel_err(ag, attn) < 1e-5
+    assert rel_err(ops.attention_bwd(g(do), g(qkv.detach()), ag, heads, d, scale), dqkv) < 2e-5
+
+
+def test_elementwise_tokens(ops):
+    x = t(37, "x", (4, 21, 784)).requires_grad_(True)
+    y = F.gelu(x)
+    dy = t(38, "dy", (4, 21, 784))
+    (dx,) = torch.autograd.grad(y, x, dy)
+    assert rel_err(ops.gelu_fwd(g(x.detach())), y) < 1e-6
+    assert rel_err(ops.gelu_bwd(g(dy), g(x.detach())), dx) < 1e-5
+    assert rel_err(ops.axpy(g(x.detach()), g(dy), 0.5), x.detach() + 0.5 * dy) < 1e-6
+    r = ops.relu_fwd(g(x.detach()))
+    assert rel_err(r, F.relu(x)) == 0.0
+    assert rel_err(ops.relu_bwd(g(dy), r), dy * (x > 0)) == 0.0
+    pe = t(39, "pe", (21, 784))
+    mt = t(40, "mt", (784,)).requires_grad_(True)
+    masked = [5, 0, 17, 9]
+    f = x + pe
+    f2 = f.clone()
+    f2[:, masked, :] = mt
+    (dxr, dmr) = torch.autograd.grad(f2, (x, mt), dy)
+    mi = torch.tensor(masked, dtype=torch.int32, device=DEV)
+    assert rel_err(ops.tokens_fwd(g(x.detach()), g(pe), g(mt.detach()), mi), f2) < 1e-6
+    dxg, dmg = ops.tokens_bwd(g(dy), mi)
+    assert rel_err(dxg, dxr) < 1e-6 and rel_err(dmg, dmr) < 1e-5
+    assert rel_err(ops.tokens_fwd(g(x.detach()), g(pe), None, None), f) < 1e-6
+
+
+@pytest.mark.parametrize("iters", [0, 1, 3])
+def test_regressor_and_loss(ops, iters):
+    B, Fd, P = 6, 1024, 66
+    feat = F.relu(t(41, "feat", (B, Fd))).requires_grad_(True)
+    fo = t(42, "fo", (B, 63), std=0.05).requires_grad_(True)
+    mean = torch.from_numpy(synth.mean_params(43))
+    w = t(44, "w", (P, Fd + P), std=0.3 * (Fd + P) ** -0.5).requires_grad_(True)
+    b = t(45, "b", (P,), std=0.05).requires_grad_(True)
+    lab = torch.from_numpy(synth.labels(46, B))
+    pred = mean.repeat(B, 1).clone()
+    pred[:, 3:] = pred[:, 3:] + fo
+    for _ in range(iters):
+        pred = pred + F.linear(torch.cat((feat, pred), 1), w, b)
+    j = pred[:, 3:].reshape(B, 21, 3)
+    j = j - j[:, 1:2]
+    out = torch.cat((pred[:, :3], j.reshape(B, 63)), 1)
+    from oracle.scat_oracle import scat_loss
+
+    loss, l3, l2, _ = scat_loss(out, lab)
+    out.retain_grad()
+    loss.backward()
+    og, preds = ops.regressor_fwd(g(feat.detach()), g(fo.detach()), g(mean).view(-1), g(w.detach()), g(b.detach()),
+                                  iters)
+    assert rel_err(og, out) < 1e-5
+    losses, dout = ops.loss_fwd_bwd(og, g(lab))
+    assert rel_err(losses, torch.stack([loss, l3, l2]).detach()) < 1e-5
+    assert rel_err(dout, out.grad) < 1e-4
+    dfeat, dfo, dw, db = ops.regressor_bwd(g(out.grad), g(feat.detach()), preds, g(w.detach()), iters)
+    assert rel_err(dfo, fo.grad) < 1e-5
+    if iters:
+        assert rel_err(dfeat, feat.grad) < 1e-5 and rel_err(dw, w.grad) < 1e-5 and rel_err(db, b.grad) < 1e-5
+
+
+def test_adam(ops):
+    n = 100003
+    p = t(47, "p", (n,))
+    gr = t(48, "g", (n,), std=1e-3)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=5e-4)
+    pg, m, v = g(p), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in (1, 2, 3):
+        ref.grad = gr * step
+        opt.step()
+        ops.adam(pg, g(gr * step), m, v, 5e-4, step)
+    assert rel_err(pg, ref.detach()) < 1e-6
+
+
+def test_errors_are_loud(ops):
+    from scat_amd._lib import ScatError
+
+    x = torch.zeros(1, 3, 8, 8)
+    with pytest.raises(ScatError):
+        ops.conv2d_fwd(x, torch.zeros(4, 3, 3, 3), 1, 1)  # CPU tensor: no fallback
+    with pytest.raises(ScatError):
+        ops.conv2d_fwd(g(x), g(torch.zeros(4, 3, 5, 5)), 1, 2)  # unsupported kernel size
