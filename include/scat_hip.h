@@ -26,6 +26,9 @@ extern "C" {
 
 int scat_version(void);
 const char* scat_last_error(void);
+/* label of the contraction-engine instantiation the last conv/gemm call on this thread launched
+ * (tile shape + loaders), for per-kernel roofline accounting in bench.py */
+const char* scat_last_kernel(void);
 /* 0 if the current device is gfx950, else SCAT_E_ARCH. */
 int scat_check_device(void);
 

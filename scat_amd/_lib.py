@@ -50,13 +50,20 @@ class _Lib:
             raise ScatError(
                 f"{LIBPATH} not found: build it with `python -m scat_amd.build` (hipcc, gfx950). "
                 "There is no CPU fallback on the product path.")
+        # torch bundles its own HIP runtime and publishes it RTLD_GLOBAL; let it initialise the device
+        # first so this library's hip* symbols resolve to that one runtime (two runtimes racing for
+        # /dev/kfd in one process end in "No HIP GPUs are available").
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
         self.cdll = ctypes.CDLL(LIBPATH)
         self.protos = parse_header()
         for name, (rt, at) in self.protos.items():
             fn = getattr(self.cdll, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = rt
             fn.argtypes = [t for t, _ in at]
-            if rt is ctypes.c_int and name not in ("scat_version",):
+            if rt is ctypes.c_int and name != "scat_version":
                 setattr(self, name, self._checked(fn, name))
             else:
                 setattr(self, name, fn)

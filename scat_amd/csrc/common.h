@@ -9,6 +9,7 @@
 namespace scat {
 
 void set_error(const char* fmt, ...);
+void set_kernel_label(const char* fmt, ...);   // which engine instantiation the last call launched
 
 // Every entry point returns through these: no exception crosses the C boundary.
 #define SCAT_REQUIRE(cond, code, ...)          \

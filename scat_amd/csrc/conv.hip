@@ -21,7 +21,10 @@ static Cfg pick_cfg(int M, int N) {
 template <int KH, int KW, bool D2>
 static void conv_gemm(const MatDesc& da, const GatherDesc& db, const OutDesc& dc, int M, int N, int K,
                       hipStream_t st) {
-    switch (pick_cfg(M, N)) {
+    const Cfg cfg = pick_cfg(M, N);
+    static const char* const names[] = {"128x128", "128x64", "64x128", "64x64"};
+    set_kernel_label("conv_gather%dx%d%s_%sx16", KH, KW, D2 ? "_d2" : "", names[cfg]);
+    switch (cfg) {
         case C128x128:
             launch_gemm<MatLoader<128, 16, true>, GatherLoader<128, 16, KH, KW, D2, false>, 128, 128, 16, 2, 2>(
                 da, db, dc, M, N, K, 1, st);
@@ -102,6 +105,7 @@ static WgradPlan wgrad_plan(int B, int Cin, int Cout, int KK, int OH, int OW) {
 template <int KH, int KW>
 static void wgrad_gemm(const WgradPlan& p, const GatherDesc& da, const GatherDesc& db, const OutDesc& dc,
                        hipStream_t st) {
+    set_kernel_label("wgrad_gather%dx%d_%dx64x32_split%d", KH, KW, p.bm, p.splits);
     if (p.bm == 64)
         launch_gemm<GatherLoader<64, 32, 1, 1, false, true>, GatherLoader<64, 32, KH, KW, false, true>, 64, 64, 32, 2,
                     2>(da, db, dc, p.M, p.N, p.K, p.splits, st);

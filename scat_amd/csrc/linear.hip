@@ -27,6 +27,7 @@ static GemmPlan gemm_plan(int M, int N, int K) {
 template <bool AK, bool BK_>
 static void gemm_dispatch(const GemmPlan& p, const MatDesc& da, const MatDesc& db, const OutDesc& dc, int M, int N,
                           int K, hipStream_t st) {
+    set_kernel_label("gemm_%c%c_%dx64x16_split%d", AK ? 'k' : 'i', BK_ ? 'k' : 'j', p.bm, p.splits);
     if (p.bm == 128)
         launch_gemm<MatLoader<128, 16, AK>, MatLoader<64, 16, BK_>, 128, 64, 16, 2, 2>(da, db, dc, M, N, K, p.splits,
                                                                                         st);

@@ -17,6 +17,15 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local char g_label[128] = "";
+
+void set_kernel_label(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_label, sizeof(g_label), fmt, ap);
+    va_end(ap);
+}
+
 static inline int grid_for(int64_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
 
 #define GRID_STRIDE(e, n) \
@@ -282,6 +291,7 @@ using namespace scat;
 
 extern "C" int scat_version(void) { return 100; }
 extern "C" const char* scat_last_error(void) { return g_err; }
+extern "C" const char* scat_last_kernel(void) { return g_label; }
 
 extern "C" int scat_check_device(void) {
     int dev = 0;

@@ -191,15 +191,16 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, i
     coef[2 * c + 1] = (float)(s2 / count);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// dx may alias dy, dres may alias dy: every element is read before it is written by the same thread
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, const float* __restrict__ x,
                                                            const float* __restrict__ yout, int relu,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
-                                                           const float* __restrict__ coef, float* __restrict__ dx,
-                                                           float* __restrict__ dres, int dres_acc, int64_t rows,
+                                                           const float* __restrict__ coef, float* dx,
+                                                           float* dres, int dres_acc, int64_t rows,
                                                            int C, int HW) {
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const int c = (int)(row % C);
@@ -210,8 +211,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             float xv = x[off + i];
             float g = bn_mask(dy[off + i], xv, yout ? yout[off + i] : 0.f, yout != nullptr, relu, sc, sh);
             float xh = (xv - mu) * is;
+            float r = (dres && dres_acc) ? dres[off + i] : 0.f;
             dx[off + i] = gi * (g - k1 - xh * k2);
-            if (dres) dres[off + i] = dres_acc ? dres[off + i] + g : g;
+            if (dres) dres[off + i] = r + g;
         }
     }
 }

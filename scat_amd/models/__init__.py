@@ -1,0 +1,2 @@
+"""Host-side mirror of the reference's ``models`` package for the reg_transformer hot path."""
+from . import hand_net, resnet, vision_transformer, vit  # noqa: F401

@@ -1,0 +1,168 @@
+"""Executor for the two attention+MLP stacks of the reference, as explicit kernel sequences:
+
+* dim-halving  ``vision_transformer.Transformer`` (models/vision_transformer.py:81-101):
+  x += Attn(LN x); non-last: x = FF(LN x) (dim -> dim//2, no residual); last: x = FF3(x).
+* dim-preserving ``vit.Transformer`` (models/vit.py:71-84): x = Attn(x)+x; x = FF(x)+x, no LN.
+
+One autograd node for the whole stack.  Per layer: LayerNorm (wave-per-row), qkv GEMM (fp32
+MFMA), LDS-resident attention core, out-projection GEMM with bias + residual fused in the
+epilogue (C += A·B + b), FF GEMMs, exact-erf GELU.  ``input_grad`` replays the tape for the
+input gradient only — that is the reference's pose-length term
+``autograd.grad(sum(feat_out), feat_visual)`` (models/hand_net.py:396) without touching weights.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from .. import ops
+
+
+@dataclass
+class LayerCfg:
+    ln1: bool          # PreNorm in front of attention
+    ff_ln: bool        # PreNorm in front of the MLP
+    ff_res: bool       # residual around the MLP
+    scale: float       # softmax scale
+    heads: int
+    dim_head: int
+
+    def nparams(self):
+        return (2 if self.ln1 else 0) + 3 + (2 if self.ff_ln else 0) + 4
+
+
+class Tape:
+    __slots__ = ("cfgs", "params", "recs", "B", "n")
+
+
+def mixer_forward(x: torch.Tensor, cfgs: List[LayerCfg], params: List[torch.Tensor], keep: bool):
+    """x[B,n,dim] -> (y[B,n,dim_out], Tape|None)."""
+    B, n, _ = x.shape
+    M = B * n
+    cur = x.contiguous().reshape(M, -1)
+    recs = []
+    pi = 0
+    for cfg in cfgs:
+        p = params[pi:pi + cfg.nparams()]
+        pi += cfg.nparams()
+        k = 0
+        if cfg.ln1:
+            g1, b1 = p[0], p[1]
+            k = 2
+            h, mu1, rs1 = ops.layernorm_fwd(cur, g1, b1)
+        else:
+            h, mu1, rs1 = cur, None, None
+        wqkv, wout, bout = p[k], p[k + 1], p[k + 2]
+        k += 3
+        inner = cfg.heads * cfg.dim_head
+        qkv = ops.linear_fwd(h, wqkv)
+        ao, attn = ops.attention_fwd(qkv.view(B, n, 3 * inner), cfg.heads, cfg.dim_head, cfg.scale)
+        x1 = cur.clone()
+        ops.linear_fwd(ao.view(M, inner), wout, bout, out=x1, accumulate=True)   # x + ao·Wᵀ + b in the epilogue
+        if cfg.ff_ln:
+            g2, b2 = p[k], p[k + 1]
+            k += 2
+            h2, mu2, rs2 = ops.layernorm_fwd(x1, g2, b2)
+        else:
+            h2, mu2, rs2 = x1, None, None
+        w0, b0, w2, bb2 = p[k], p[k + 1], p[k + 2], p[k + 3]
+        u = ops.linear_fwd(h2, w0, b0)
+        a = ops.gelu_fwd(u)
+        if cfg.ff_res:
+            x2 = x1.clone()
+            ops.linear_fwd(a, w2, bb2, out=x2, accumulate=True)
+        else:
+            x2 = ops.linear_fwd(a, w2, bb2)
+        if keep:
+            recs.append((cur, h, mu1, rs1, qkv, attn, ao, x1, h2, mu2, rs2, u, a))
+        cur = x2
+    y = cur.view(B, n, -1)
+    tape = None
+    if keep:
+        tape = Tape()
+        tape.cfgs, tape.params, tape.recs, tape.B, tape.n = cfgs, params, recs, B, n
+    return y, tape
+
+
+def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
+    """-> (dx[B,n,dim], [param grads in ``params`` order] or None)."""
+    B, n = tape.B, tape.n
+    M = B * n
+    d = dy.contiguous().reshape(M, -1)
+    grads: List[Optional[torch.Tensor]] = [None] * len(tape.params)
+    pi = len(tape.params)
+    for cfg, rec in zip(reversed(tape.cfgs), reversed(tape.recs)):
+        cur, h, mu1, rs1, qkv, attn, ao, x1, h2, mu2, rs2, u, a = rec
+        npar = cfg.nparams()
+        pi -= npar
+        p = tape.params[pi:pi + npar]
+        k = (2 if cfg.ln1 else 0)
+        wqkv, wout = p[k], p[k + 1]
+        kf = k + 3 + (2 if cfg.ff_ln else 0)
+        w0, w2 = p[kf], p[kf + 2]
+        inner = cfg.heads * cfg.dim_head
+        # ---- MLP
+        da = ops.linear_dgrad(d, w2)
+        if want_param_grads:
+            grads[pi + kf + 2] = ops.linear_wgrad(d, a)
+            grads[pi + kf + 3] = ops.colsum(d)
+        du = ops.gelu_bwd(da, u)
+        if want_param_grads:
+            grads[pi + kf] = ops.linear_wgrad(du, h2)
+            grads[pi + kf + 1] = ops.colsum(du)
+        dh2 = ops.linear_dgrad(du, w0)
+        if cfg.ff_ln:
+            dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, p[k + 3], mu2, rs2)
+            if want_param_grads:
+                grads[pi + k + 3], grads[pi + k + 4] = dg2, db2
+        else:
+            dx1 = dh2
+        if cfg.ff_res:
+            dx1 = ops.axpy(dx1, d, 1.0, out=dx1)
+        # ---- attention: x1 = x + ao·Woutᵀ + b
+        if want_param_grads:
+            grads[pi + k + 1] = ops.linear_wgrad(dx1, ao.view(M, inner))
+            grads[pi + k + 2] = ops.colsum(dx1)
+        dao = ops.linear_dgrad(dx1, wout)
+        dqkv = ops.attention_bwd(dao.view(B, n, inner), qkv.view(B, n, 3 * inner), attn, cfg.heads, cfg.dim_head,
+                                 cfg.scale).view(M, 3 * inner)
+        if want_param_grads:
+            grads[pi + k] = ops.linear_wgrad(dqkv, h)
+        dh = ops.linear_dgrad(dqkv, wqkv)
+        if cfg.ln1:
+            dx, dg1, db1 = ops.layernorm_bwd(dh, cur, p[0], mu1, rs1)
+            if want_param_grads:
+                grads[pi], grads[pi + 1] = dg1, db1
+        else:
+            dx = dh
+        d = ops.axpy(dx, dx1, 1.0, out=dx)
+    return d.view(B, n, -1), (grads if want_param_grads else None)
+
+
+class TapeHolder:
+    """Mutable slot the autograd node fills so the owning module can replay the tape."""
+    tape: Optional[Tape] = None
+    want_tape: bool = False   # keep the tape even when nothing requires grad (pose-length term in eval mode)
+
+
+class _MixerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, holder, cfgs, *params):
+        keep = any(ctx.needs_input_grad) or holder.want_tape
+        y, tape = mixer_forward(x, cfgs, list(params), keep)
+        ctx.tape = tape
+        holder.tape = tape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.tape is None:
+            raise RuntimeError("scat_amd: mixer backward without a recorded forward")
+        dx, grads = mixer_backward(ctx.tape, dy, True)
+        return (dx if ctx.needs_input_grad[0] else None, None, None, *grads)
+
+
+def run_mixer(x, holder, cfgs, params):
+    return _MixerFn.apply(x, holder, cfgs, *params)

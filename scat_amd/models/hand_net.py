@@ -1,0 +1,141 @@
+"""``EncoderTransformer`` — the reference's ``reg_transformer`` network (models/hand_net.py:315-398 of
+tomguluson92/SCAT) with the same constructor ``(opt, mean_params)``, attribute names, ``state_dict``
+keys (356 entries for ResNet-50) and return tuple ``(pred_params[B,66], feat_visual[B,21,28,28]
+[, pl_term[B,21,28,28]])``, running on libscat_hip:
+
+    ResNet-50 (one fused node) -> conv1x1 512->21 on x2 -> tokens (+PE, mask-token scatter)
+    -> dim-halving transformer (one fused node) -> 63 offsets on the mean template
+    -> ``iteration`` x Linear(1090->66) residual refinement -> root-relative joints.
+
+Quirks kept on purpose: masking draws from python ``random`` exactly like the
+reference (also in eval mode); ``mean_params`` is a plain attribute moved with ``.cuda()`` in the
+constructor; ``pl_term`` carries no gradient.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import nn as snn
+from .. import ops
+from . import resnet, vision_transformer
+
+
+def get_model(arch):
+    if hasattr(resnet, arch):
+        return getattr(resnet, arch)(pretrained=True, num_classes=512)
+    raise ValueError("Invalid Backbone Architecture")
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoidal table as a ``pe`` buffer [1,max_len,d_model] (models/hand_net.py:61-77)."""
+
+    def __init__(self, d_model, dropout=0.0, max_len=5000):
+        super().__init__()
+        self.dropout = snn.Dropout(p=dropout)
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-np.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+    def forward(self, x):
+        # the reference slices dim 0 of the [1,L,D] buffer with the batch size => always the whole table
+        return _TokensFn.apply(x, self.pe[0], None, None)
+
+
+class _TokensFn(torch.autograd.Function):
+    """x + pe, then rows ``masked`` <- mask_token (models/hand_net.py:366-373), one pass."""
+
+    @staticmethod
+    def forward(ctx, x, pe, mask_token, midx):
+        x = x.contiguous()
+        ctx.midx = midx
+        ctx.has_mask = mask_token is not None and midx is not None and midx.numel() > 0
+        mt = mask_token.reshape(-1) if ctx.has_mask else None
+        return ops.tokens_fwd(x, pe, mt, midx if ctx.has_mask else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, dm = ops.tokens_bwd(dy.contiguous(), ctx.midx if ctx.has_mask else None, want_dmask=ctx.has_mask)
+        return dx, None, (dm.view(1, 1, -1) if ctx.has_mask else None), None
+
+
+class _RegressorFn(torch.autograd.Function):
+    """mean template + offsets, ``iters`` residual Linear(1090->66) steps, root-relative joints
+    (models/hand_net.py:379-393) as one kernel per direction."""
+
+    @staticmethod
+    def forward(ctx, feat, feat_out, mean, w, b, iters):
+        feat, feat_out, w = feat.contiguous(), feat_out.contiguous(), w.contiguous()
+        out, preds = ops.regressor_fwd(feat, feat_out, mean, w, b, iters)
+        ctx.save_for_backward(feat, preds, w)
+        ctx.iters = iters
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, preds, w = ctx.saved_tensors
+        dfeat, dfo, dw, db = ops.regressor_bwd(dout.contiguous(), feat, preds, w, ctx.iters)
+        return dfeat, dfo, None, dw, db, None
+
+
+class EncoderTransformer(nn.Module):
+    def __init__(self, opt, mean_params):
+        super().__init__()
+        self.mean_params = mean_params.clone().cuda()
+        heads = opt.vit_heads
+        self.pl = opt.pl_reg
+        self.full_content = 21
+        self.conv1x1_channel_reduction = snn.Conv2d(512, 21, 1, 1, 0, bias=False)
+        self.transformer = vision_transformer.Transformer(dim=784, depth=3, heads=heads, dim_head=64, mlp_dim=392,
+                                                          dropout=0.0)
+        self.main_encoder = get_model("resnet50")
+        self.iteration = opt.iteration
+        self.pos_embed = opt.pos_embed
+        self.positionalEncoding = PositionalEncoding(784, max_len=21)
+        self.mask_token = nn.Parameter(torch.randn(1, 1, 784))
+        self.mask_rate = opt.mask_rate
+        self.regressor = snn.Linear(1024 + 66, 66)
+        self._midx_cache = {}
+
+    def _draw_mask(self, device):
+        """python-``random`` draw sequence of models/hand_net.py:369-372."""
+        if not (0.1 <= self.mask_rate <= 0.9):
+            return None
+        masked = list(range(self.full_content))
+        random.shuffle(masked)
+        masked = tuple(masked[: int(self.mask_rate * self.full_content)])
+        if not masked:
+            return None
+        key = (masked, str(device))
+        t = self._midx_cache.get(key)
+        if t is None:
+            if len(self._midx_cache) > 4096:
+                self._midx_cache.clear()
+            t = torch.tensor(masked, dtype=torch.int32, device=device)
+            self._midx_cache[key] = t
+        return t
+
+    def forward(self, main_input):
+        main_feat, x1, x2, x3, x4 = self.main_encoder(main_input)
+        feat_visual = self.conv1x1_channel_reduction(x2)                      # [B,21,28,28]
+        B = feat_visual.size(0)
+        midx = self._draw_mask(feat_visual.device)
+        pe = self.positionalEncoding.pe[0] if self.pos_embed else None
+        tokens = _TokensFn.apply(feat_visual.view(B, 21, -1), pe, self.mask_token, midx)
+        self.transformer._holder.want_tape = bool(self.pl)
+        feat_out = self.transformer(tokens, None)                             # [B,21,3]
+        pred_params = _RegressorFn.apply(main_feat, feat_out.reshape(B, -1), self.mean_params.reshape(-1),
+                                         self.regressor.weight, self.regressor.bias, self.iteration)
+        if self.pl:
+            # d sum(feat_out) / d feat_visual, no graph (hand_net.py:396): replay the mixer tape for the
+            # input gradient only, then undo the token scatter.
+            dtok = self.transformer.input_grad(torch.ones_like(feat_out))
+            pl_term = ops.tokens_bwd(dtok.contiguous(), midx, want_dmask=False)[0].view_as(feat_visual)
+            return pred_params, feat_visual, pl_term
+        return pred_params, feat_visual

@@ -1,0 +1,278 @@
+"""ResNet backbone with the reference's interface (models/resnet.py:103-222 of tomguluson92/SCAT):
+same class/attribute names, constructor arguments, ``state_dict`` keys and the 5-tuple
+``(feat[B,1024], x1, x2, x3, x4)`` return — executed as ONE autograd node whose forward and
+backward are explicit sequences of libscat_hip kernels.
+
+MI355X design (not a translation of the reference's module-by-module call graph):
+* BatchNorm batch statistics are one HBM pass; the normalise+ReLU of bn1/bn2 is never
+  materialised — it is folded into the operand load of the consuming conv (forward) and of the
+  weight-gradient contraction (backward), and the ReLU mask is recomputed from the raw conv
+  output in the BN backward.  Only block outputs (needed as residuals and returned as x1..x4)
+  are written.
+* The stem's BN+ReLU is folded into the max-pool load.
+* Weight gradients are produced by a deterministic split-K contraction (fixed-order slab
+  reduction, no float atomics), optionally straight into a flat gradient bucket that the
+  data-parallel layer all-reduces on a side stream while earlier layers still run.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import nn as snn
+from .. import ops
+
+__all__ = ["ResNet", "Bottleneck", "resnet50", "resnet101", "resnet152"]
+
+
+class Bottleneck(nn.Module):
+    """Parameter layout of models/resnet.py:62-76 (stride on the 3x3)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = snn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = snn.BatchNorm2d(planes)
+        self.conv2 = snn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = snn.BatchNorm2d(planes)
+        self.conv3 = snn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = snn.BatchNorm2d(planes * 4)
+        self.relu = snn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+
+def _bn_buffers(bn):
+    return bn.running_mean, bn.running_var
+
+
+class _BNState:
+    """Per-BN tensors produced in forward and consumed in backward."""
+    __slots__ = ("mean", "invstd", "scale", "shift")
+
+    def __init__(self, x, bn, training):
+        if training:
+            self.mean, self.invstd, self.scale, self.shift = ops.bn_train_stats(
+                x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+            bn.num_batches_tracked += 1
+        else:
+            self.scale, self.shift = ops.bn_eval_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            self.mean = self.invstd = None
+
+
+class _BackboneFn(torch.autograd.Function):
+    """ResNet.forward (models/resnet.py:142-162) + its whole backward as one node."""
+
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        training = net.training
+        x = x if x.is_contiguous() else x.contiguous()
+        tape = []
+        # stem: conv7x7/2 -> [BN -> ReLU -> maxpool fused]
+        c0 = ops.conv2d_fwd(x, net.conv1.weight, 2, 3)
+        s0 = _BNState(c0, net.bn1, training)
+        cur, idx0 = ops.maxpool_fwd(c0, s0.scale, s0.shift, True)
+        feats = []
+        for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+            for blk in layer:
+                xin = cur
+                c1 = ops.conv2d_fwd(xin, blk.conv1.weight, 1, 0)
+                s1 = _BNState(c1, blk.bn1, training)
+                c2 = ops.conv2d_fwd(c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True)
+                s2 = _BNState(c2, blk.bn2, training)
+                c3 = ops.conv2d_fwd(c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True)
+                s3 = _BNState(c3, blk.bn3, training)
+                if blk.downsample is not None:
+                    cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0)
+                    sd = _BNState(cd, blk.downsample[1], training)
+                    res = ops.bn_apply(cd, sd.scale, sd.shift, None, False)
+                else:
+                    cd = sd = None
+                    res = xin
+                cur = ops.bn_apply(c3, s3.scale, s3.shift, res, True)
+                tape.append((blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, cur))
+            feats.append(cur)
+        pooled = ops.avgpool_fwd(cur, relu=True)                      # AvgPool2d(7) -> view -> relu
+        fc = ops.linear_fwd(pooled, net.fc1.weight, net.fc1.bias)
+        feat = ops.relu_fwd(fc)
+        if training and any(ctx.needs_input_grad):
+            # Tensors that are also OUTPUTS of this node (x1..x4) go through save_for_backward (no
+            # ctx<->output reference cycle); the tape keeps their index instead.
+            def unhook(t):
+                for k, f in enumerate(feats):
+                    if t is f:
+                        return k
+                return t
+            ctx.tape = [tuple(unhook(v) if isinstance(v, torch.Tensor) else v for v in rec) for rec in tape]
+            ctx.net = net
+            ctx.stem = (x, c0, s0, idx0)
+            ctx.tail = (pooled,)
+            ctx.save_for_backward(feat, *feats)
+        else:
+            ctx.net = None
+        return (feat, *feats)
+
+    @staticmethod
+    def backward(ctx, dfeat, dx1, dx2, dx3, dx4):
+        net = ctx.net
+        if net is None:
+            raise RuntimeError("scat_amd: backbone backward needs a training-mode forward (BN batch statistics)")
+        feat, *outs = ctx.saved_tensors
+        (pooled,) = ctx.tail
+        tape = [tuple(outs[v] if isinstance(v, int) else v for v in rec) for rec in ctx.tape]
+        sink = getattr(net, "_grad_sink", None)   # flat gradient buckets (scat_amd.dp.GradBuckets), or None
+        grads = {}
+        if sink is not None:
+            sink.begin_backbone()
+
+        def gbuf(p):
+            return sink.view_for(p) if sink is not None else None
+
+        def put(p, g):
+            grads[p] = g
+
+        stage_grads = [dx1, dx2, dx3, dx4]
+        # ---- tail: relu(fc1(relu(avgpool(x4))))
+        x4 = tape[-1][-1]
+        if dfeat is not None:
+            dfc = ops.relu_bwd(dfeat if dfeat.is_contiguous() else dfeat.contiguous(), feat)
+            put(net.fc1.weight, ops.linear_wgrad(dfc, pooled, out=gbuf(net.fc1.weight)))
+            put(net.fc1.bias, ops.colsum(dfc, out=gbuf(net.fc1.bias)))
+            dpool = ops.linear_dgrad(dfc, net.fc1.weight)
+            dcur = ops.avgpool_bwd(dpool, pooled, tuple(x4.shape), relu=True)
+        else:
+            dcur = torch.zeros_like(x4)
+        if sink is not None:
+            sink.ready(("fc1",))
+        # ---- residual stages, last block first
+        layers = (net.layer1, net.layer2, net.layer3, net.layer4)
+        li = 3
+        remaining = len(layers[li])
+        ext = stage_grads[li]
+        if ext is not None:
+            dcur = ops.axpy(dcur, ext.contiguous(), 1.0, out=dcur)
+        for rec in reversed(tape):
+            blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out = rec
+            # out = relu(bn3(c3) + res): g = dcur * (out>0) is also the residual branch's gradient
+            dc3, dg, db = ops.bn_bwd(dcur, c3, out, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
+                                     gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), dres=dcur)
+            put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
+            g = dcur
+            put(blk.conv3.weight, ops.conv2d_wgrad(dc3, c2, tuple(blk.conv3.weight.shape), 1, 0, s2.scale, s2.shift,
+                                                   True, out=gbuf(blk.conv3.weight)))
+            da2 = ops.conv2d_dgrad(dc3, ops.conv2d_wt(blk.conv3.weight), tuple(c2.shape),
+                                   tuple(blk.conv3.weight.shape), 1, 0)
+            del dc3
+            dc2, dg, db = ops.bn_bwd(da2, c2, None, True, s2.scale, s2.shift, s2.mean, s2.invstd, blk.bn2.weight,
+                                     gbuf(blk.bn2.weight), gbuf(blk.bn2.bias), dx=da2)
+            put(blk.bn2.weight, dg), put(blk.bn2.bias, db)
+            put(blk.conv2.weight, ops.conv2d_wgrad(dc2, c1, tuple(blk.conv2.weight.shape), blk.stride, 1, s1.scale,
+                                                   s1.shift, True, out=gbuf(blk.conv2.weight)))
+            da1 = ops.conv2d_dgrad(dc2, ops.conv2d_wt(blk.conv2.weight), tuple(c1.shape),
+                                   tuple(blk.conv2.weight.shape), blk.stride, 1)
+            del dc2, da2
+            dc1, dg, db = ops.bn_bwd(da1, c1, None, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight,
+                                     gbuf(blk.bn1.weight), gbuf(blk.bn1.bias), dx=da1)
+            put(blk.bn1.weight, dg), put(blk.bn1.bias, db)
+            put(blk.conv1.weight, ops.conv2d_wgrad(dc1, xin, tuple(blk.conv1.weight.shape), 1, 0,
+                                                   out=gbuf(blk.conv1.weight)))
+            if cd is not None:
+                dsw, dsbn = blk.downsample[0].weight, blk.downsample[1]
+                dcd, dg, db = ops.bn_bwd(g, cd, None, False, sd.scale, sd.shift, sd.mean, sd.invstd, dsbn.weight,
+                                         gbuf(dsbn.weight), gbuf(dsbn.bias), dx=g)
+                put(dsbn.weight, dg), put(dsbn.bias, db)
+                put(dsw, ops.conv2d_wgrad(dcd, xin, tuple(dsw.shape), blk.stride, 0, out=gbuf(dsw)))
+                dxin = ops.conv2d_dgrad(dcd, ops.conv2d_wt(dsw), tuple(xin.shape), tuple(dsw.shape), blk.stride, 0)
+                del dcd
+            else:
+                dxin = g
+            dcur = ops.conv2d_dgrad(dc1, ops.conv2d_wt(blk.conv1.weight), tuple(xin.shape),
+                                    tuple(blk.conv1.weight.shape), 1, 0, out=dxin, accumulate=True)
+            del dc1, da1, g
+            remaining -= 1
+            if remaining == 0:
+                if sink is not None:
+                    sink.ready(("layer%d" % (li + 1),))
+                li -= 1
+                if li >= 0:
+                    remaining = len(layers[li])
+                    ext = stage_grads[li]
+                    if ext is not None:
+                        dcur = ops.axpy(dcur, ext.contiguous(), 1.0, out=dcur)
+        # ---- stem: maxpool <- relu <- bn1 <- conv1
+        x, c0, s0, idx0 = ctx.stem
+        da0 = ops.maxpool_bwd(dcur, idx0, tuple(c0.shape))
+        dc0, dg, db = ops.bn_bwd(da0, c0, None, True, s0.scale, s0.shift, s0.mean, s0.invstd, net.bn1.weight,
+                                 gbuf(net.bn1.weight), gbuf(net.bn1.bias), dx=da0)
+        put(net.bn1.weight, dg), put(net.bn1.bias, db)
+        put(net.conv1.weight, ops.conv2d_wgrad(dc0, x, tuple(net.conv1.weight.shape), 2, 3,
+                                               out=gbuf(net.conv1.weight)))
+        ctx.tape = ctx.stem = ctx.tail = None
+        # the input image needs no gradient on this path (train.py feeds data, not a leaf)
+        if sink is not None:
+            # gradients already sit in the flat buckets (and may be mid all-reduce on the RCCL stream):
+            # hand them to the parameters directly instead of through AccumulateGrad copies
+            sink.ready(("stem",))
+            sink.adopt(net._flat_params)
+            return (None, None, *[None for _ in net._flat_params])
+        return (None, None, *[grads.get(p) for p in net._flat_params])
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=1000):
+        # num_classes is accepted and ignored, exactly like the reference (resnet.py:103,116)
+        self.inplanes = 64
+        super().__init__()
+        self.conv1 = snn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = snn.BatchNorm2d(64)
+        self.relu = snn.ReLU(inplace=True)
+        self.maxpool = nn.Identity()   # placeholder attribute; pooling runs inside the fused node
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.Identity()
+        self.fc1 = snn.Linear(512 * block.expansion, 1024)
+        for m in self.modules():   # same initialisers as resnet.py:118-123
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self._flat_params = None
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                snn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                snn.BatchNorm2d(planes * block.expansion))
+        seq = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        seq += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    def forward(self, x):
+        if x.shape[-1] != 224 or x.shape[-2] != 224:
+            # AvgPool2d(7)+fc1(2048) fix the geometry to 224x224 in the reference too (resnet.py:115-116)
+            raise RuntimeError(f"scat_amd ResNet expects 224x224 input like the reference, got {tuple(x.shape)}")
+        self._flat_params = list(self.parameters())
+        return _BackboneFn.apply(x, self, *self._flat_params)
+
+
+def _make(layers, pretrained, **kwargs):
+    # pretrained=True downloads ImageNet weights in the reference (resnet.py:194); there is no
+    # network on the GPU box, so weights come from load_state_dict (keys are identical).
+    return ResNet(Bottleneck, layers, **kwargs)
+
+
+def resnet50(pretrained=False, **kwargs):
+    return _make([3, 4, 6, 3], pretrained, **kwargs)
+
+
+def resnet101(pretrained=False, **kwargs):
+    return _make([3, 4, 23, 3], pretrained, **kwargs)
+
+
+def resnet152(pretrained=False, **kwargs):
+    return _make([3, 8, 36, 3], pretrained, **kwargs)

@@ -1,0 +1,202 @@
+"""Parameter-holder modules and single-op autograd Functions on the HIP library.
+
+The module classes subclass torch.nn containers ONLY to inherit parameter registration,
+``state_dict`` key layout and default initialisation (so checkpoints interchange with the
+reference). Their ``forward`` always runs libscat_hip kernels; there is no torch
+compute fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d forward/backward (models/resnet.py:65-72; hand_net.py:329) on the MFMA engine."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad):
+        x, w = _c(x), _c(w)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, bias is not None)
+        return ops.conv2d_fwd(x, w, stride, pad, bias=bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, has_bias = ctx.cfg
+        dy = _c(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_dgrad(dy, ops.conv2d_wt(w), tuple(x.shape), tuple(w.shape), stride, pad)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad)
+        if has_bias and ctx.needs_input_grad[2]:
+            B, C, H, W = dy.shape
+            db = ops.colsum(_c(dy.permute(0, 2, 3, 1).reshape(-1, C)))
+        return dx, dw, db, None, None
+
+
+class _LinearFn(torch.autograd.Function):
+    """nn.Linear (models/resnet.py:116; hand_net.py:353; vision_transformer.py:33-35)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x2 = _c(x).reshape(-1, x.shape[-1])
+        w = _c(w)
+        ctx.save_for_backward(x2, w)
+        ctx.shape = x.shape
+        ctx.has_bias = bias is not None
+        return ops.linear_fwd(x2, w, bias).reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = _c(dy).reshape(-1, dy.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_dgrad(dy2, w).reshape(ctx.shape)
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear_wgrad(dy2, x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy2)
+        return dx, dw, db
+
+
+class _ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.relu_fwd(_c(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.relu_bwd(_c(dy), y)
+
+
+class _GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return ops.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_bwd(_c(dy), x)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        x2 = _c(x).reshape(-1, x.shape[-1])
+        y, mean, rstd = ops.layernorm_fwd(x2, g, b, eps)
+        ctx.save_for_backward(x2, g, mean, rstd)
+        ctx.shape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(_c(dy).reshape(x2.shape), x2, g, mean, rstd)
+        return dx.reshape(ctx.shape), dg, db, None
+
+
+class _BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm2d (+ optional fused ReLU), train and eval (models/resnet.py:68-73)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, training, momentum, eps, relu):
+        x = _c(x)
+        if training:
+            mean, invstd, scale, shift = ops.bn_train_stats(x, gamma, beta, rm, rv, momentum, eps)
+        else:
+            scale, shift = ops.bn_eval_fold(gamma, beta, rm, rv, eps)
+            mean = invstd = None
+        y = ops.bn_apply(x, scale, shift, None, relu)
+        ctx.training, ctx.relu = training, relu
+        if training:
+            ctx.save_for_backward(x, gamma, mean, invstd, scale, shift)
+        else:
+            ctx.save_for_backward(x, gamma, scale, shift)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        if ctx.training:
+            x, gamma, mean, invstd, scale, shift = ctx.saved_tensors
+            dx, dg, db = ops.bn_bwd(dy, x, None, ctx.relu, scale, shift, mean, invstd, gamma)
+            return dx, dg, db, None, None, None, None, None, None
+        raise RuntimeError("scat_amd: BatchNorm backward in eval mode is not on the reference's path "
+                           "(eval.py runs forward only)")
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0):
+    return _Conv2dFn.apply(x, w, bias, stride, pad)
+
+
+def linear(x, w, bias=None):
+    return _LinearFn.apply(x, w, bias)
+
+
+class Conv2d(nn.Conv2d):
+    def forward(self, x):
+        assert self.kernel_size[0] == self.kernel_size[1] and self.stride[0] == self.stride[1]
+        assert self.dilation == (1, 1) and self.groups == 1
+        return conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0])
+
+
+class Linear(nn.Linear):
+    def forward(self, x):
+        return linear(x, self.weight, self.bias)
+
+
+class ReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+
+    def forward(self, x):
+        return _ReluFn.apply(x)
+
+
+class GELU(nn.Module):
+    def forward(self, x):
+        return _GeluFn.apply(x)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x):
+        return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    fuse_relu = False
+
+    def forward(self, x):
+        if self.training and self.track_running_stats:
+            self.num_batches_tracked += 1
+        return _BatchNormFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                  self.momentum, self.eps, self.fuse_relu)
+
+
+class Dropout(nn.Module):
+    """p = 0 everywhere on the reference's reg_transformer path (hand_net.py:331 dropout=0.0)."""
+
+    def __init__(self, p=0.0):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if self.p > 0 and self.training:
+            raise NotImplementedError("scat_amd: dropout p>0 in training is not implemented on the HIP path")
+        return x

@@ -12,6 +12,21 @@ from ._lib import ScatError, lib
 
 _ws_cache = {}
 
+# bench.py sets PROFILE = [] for one instrumented step: every contraction-engine call then appends
+# (kernel label, algorithmic FLOPs, start event, end event) — HIP events on the launch stream.
+PROFILE = None
+
+
+def _prof(flops, fn, *args):
+    if PROFILE is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn(*args)
+    e1.record()
+    PROFILE.append((lib().scat_last_kernel().decode(), float(flops), e0, e1))
+    return r
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -53,8 +68,8 @@ def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, b
     Cout, _, KH, KW = w.shape
     OH, OW = conv_out_hw(H, W, KH, stride, pad)
     y = out if out is not None else torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
-    lib().scat_conv2d_fwd(_p(x), _p(w), _p(bias), _p(y), B, Cin, H, W, Cout, KH, KW, stride, pad,
-                          _p(in_scale), _p(in_shift), int(in_relu), _stream())
+    _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_fwd, _p(x), _p(w), _p(bias), _p(y), B, Cin, H, W,
+          Cout, KH, KW, stride, pad, _p(in_scale), _p(in_shift), int(in_relu), _stream())
     return y
 
 
@@ -71,8 +86,9 @@ def conv2d_dgrad(dy, wt, x_shape, w_shape, stride, pad, out=None, accumulate=Fal
     B, Cin, H, W = x_shape
     Cout, _, KH, KW = w_shape
     dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
-    lib().scat_conv2d_dgrad(_p(dy), _p(wt), _p(dx), B, Cin, H, W, Cout, KH, KW, stride, pad, int(accumulate),
-                            _stream())
+    OH, OW = conv_out_hw(H, W, KH, stride, pad)
+    _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_dgrad, _p(dy), _p(wt), _p(dx), B, Cin, H, W,
+          Cout, KH, KW, stride, pad, int(accumulate), _stream())
     return dx
 
 
@@ -83,8 +99,9 @@ def conv2d_wgrad(dy, x, w_shape, stride, pad, in_scale=None, in_shift=None, in_r
     dw = out if out is not None else torch.empty(w_shape, dtype=torch.float32, device=x.device)
     need = lib().scat_conv2d_wgrad_ws(B, Cin, H, W, Cout, KH, KW, stride, pad)
     ws = workspace(need, x.device)
-    lib().scat_conv2d_wgrad(_p(dy), _p(x), _p(dw), B, Cin, H, W, Cout, KH, KW, stride, pad, _p(in_scale),
-                            _p(in_shift), int(in_relu), _p(ws), ws.numel(), _stream())
+    OH, OW = conv_out_hw(H, W, KH, stride, pad)
+    _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_wgrad, _p(dy), _p(x), _p(dw), B, Cin, H, W,
+          Cout, KH, KW, stride, pad, _p(in_scale), _p(in_shift), int(in_relu), _p(ws), ws.numel(), _stream())
     return dw
 
 
@@ -93,18 +110,18 @@ def conv2d_wgrad(dy, x, w_shape, stride, pad, in_scale=None, in_shift=None, in_r
 def gemm(a, a_si, a_sk, b, b_sk, b_sj, c, c_si, c_sj, M, N, K, bias=None, bias_mode=0, accumulate=False):
     need = lib().scat_gemm_ws(M, N, K)
     ws = workspace(need, c.device) if need else None
-    lib().scat_gemm(_p(a), a_si, a_sk, _p(b), b_sk, b_sj, _p(c), c_si, c_sj, M, N, K, _p(bias), bias_mode,
-                    int(accumulate), _p(ws), ws.numel() if ws is not None else 0, _stream())
+    _prof(2.0 * M * N * K, lib().scat_gemm, _p(a), a_si, a_sk, _p(b), b_sk, b_sj, _p(c), c_si, c_sj, M, N, K, _p(bias),
+          bias_mode, int(accumulate), _p(ws), ws.numel() if ws is not None else 0, _stream())
     return c
 
 
-def linear_fwd(x2d, w, bias=None, out=None):
-    """y[M,N] = x[M,K] @ w[N,K]^T + bias"""
+def linear_fwd(x2d, w, bias=None, out=None, accumulate=False):
+    """y[M,N] (+)= x[M,K] @ w[N,K]^T + bias"""
     _chk(x2d, w, bias, out)
     M, K = x2d.shape
     N = w.shape[0]
     y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=x2d.device)
-    return gemm(x2d, K, 1, w, 1, K, y, N, 1, M, N, K, bias, 2 if bias is not None else 0)
+    return gemm(x2d, K, 1, w, 1, K, y, N, 1, M, N, K, bias, 2 if bias is not None else 0, accumulate)
 
 
 def linear_dgrad(dy2d, w, out=None, accumulate=False):

@@ -1,0 +1,87 @@
+"""The reference's train step (train.py:136-209), restated for the benchmark and parity harness.
+
+train.py itself needs torchvision / warmup_scheduler / oss2 / MANO assets that are not shipped, so
+its inner iteration is restated here line by line in meaning (citations inline):
+zero_grad -> net(inputs) -> orthographic projection + MSE/L1 loss (+ the constant pose-length
+term) -> backward -> Adam.  Differences are only in *how* it runs on MI355X: the loss forward and
+its gradient are one kernel, Adam is one launch over a flat parameter buffer, and in
+data-parallel runs gradient buckets are all-reduced over RCCL while backward is still running.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .dp import GradBuckets
+
+
+class _LossFn(torch.autograd.Function):
+    """w3d*MSE(3-D) + w2d*L1(2-D after batch_orth_proj_idrot*112+112) — train.py:165-203."""
+
+    @staticmethod
+    def forward(ctx, out, labels, w3d, w2d):
+        losses, dout = ops.loss_fwd_bwd(out.contiguous(), labels.contiguous(), w3d, w2d)
+        ctx.save_for_backward(dout)
+        ctx.mark_non_differentiable(losses)
+        return losses[0].clone(), losses
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (dout,) = ctx.saved_tensors
+        return dout * g, None, None, None
+
+
+def scat_loss(outputs, labels, w3d=100000.0, w2d=10.0):
+    """-> (loss scalar with grad, tensor [loss, l_3d, l_2d])."""
+    return _LossFn.apply(outputs, labels, w3d, w2d)
+
+
+def pose_length_term(pl_term):
+    """train.py:178-183.  A constant w.r.t. the parameters (pl_term has no graph): reported, adds no
+    gradient.  Tiny host-side tensor arithmetic on [B,21,28,28]."""
+    pl_len = pl_term.square().sum(dim=[2, 3]).mean(dim=[1]).sqrt()
+    pl_mean = 0.01 * pl_len.mean()
+    return (pl_len - pl_mean).square().mean()
+
+
+class FusedAdam:
+    """torch.optim.Adam(params, lr) defaults (train.py:60) as one kernel over the flat buffers."""
+
+    def __init__(self, buckets: GradBuckets, lr=5e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.b = buckets
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.m = torch.zeros_like(buckets.flat_param)
+        self.v = torch.zeros_like(buckets.flat_param)
+        self.t = 0
+
+    def zero_grad(self):
+        self.b.zero_grad()
+
+    def step(self):
+        self.b.finish()            # compute stream waits for the RCCL stream here
+        self.t += 1
+        ops.adam(self.b.flat_param, self.b.flat_grad, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1],
+                 self.eps)
+
+
+class TrainStep:
+    """One object per process/GPU: model + flat buckets + fused Adam; ``__call__(inputs, labels)``
+    runs exactly one train.py inner iteration and returns the loss tensors (no host sync)."""
+
+    def __init__(self, net, lr=5e-4, w3d=100000.0, w2d=10.0, process_group=None):
+        self.net = net
+        self.buckets = GradBuckets(net, process_group)
+        self.opt = FusedAdam(self.buckets, lr)
+        self.w3d, self.w2d = w3d, w2d
+
+    def __call__(self, inputs, labels):
+        self.opt.zero_grad()                                   # train.py:154
+        out = self.net(inputs)                                 # train.py:158-161
+        pred = out[0]
+        loss, parts = scat_loss(pred, labels, self.w3d, self.w2d)
+        l_pl = pose_length_term(out[2]) if len(out) == 3 else None
+        if l_pl is not None:
+            loss = loss + 10 * l_pl                            # train.py:200-201 (no gradient)
+        loss.backward()                                        # train.py:206
+        self.opt.step()                                        # train.py:209
+        return loss.detach(), parts, l_pl, pred.detach()

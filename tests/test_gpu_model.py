@@ -1,0 +1,244 @@
+"""Model-level parity on a real MI355X, through the C ABI: the HIP path against
+(a) the committed outputs of the REAL reference modules (tests/golden, made by oracle/gen_golden.py)
+(b) the CPU oracle on the same seeded inputs at other sizes.
+
+Bar (BASELINE.json north_star): 21-joint offsets pred[:,3:66] within 1e-4 relative (norm-wise,
+max|a-b|/max|b|) of the reference CPU fp32 path; MPJPE within 1e-4 relative."""
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scat_oracle as O
+from oracle.util import digest, digest_err, rel_err
+from scat_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+
+def opt_ns(**kw):
+    d = dict(vit_heads=8, pl_reg=True, iteration=3, pos_embed=True, mask_rate=0.2, vit_depth=3)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def make_encoder(seed, **kw):
+    from scat_amd.models.hand_net import EncoderTransformer
+
+    net = EncoderTransformer(opt_ns(**kw), T(synth.mean_params(seed)))
+    net.load_state_dict(synth.to_torch(synth.encoder_transformer_state(seed, kw.get("vit_heads", 8))), strict=True)
+    return net.cuda()
+
+
+def test_vt_transformer_golden(golden):
+    from scat_amd.models import vision_transformer as VT
+
+    g = golden("vt")
+    net = VT.Transformer(dim=784, depth=3, heads=8, dim_head=64, mlp_dim=392, dropout=0.0)
+    net.load_state_dict(synth.to_torch(synth.vt_state(11, "", 784, 3, 8, 64)), strict=True)
+    net.cuda()
+    x = T(synth.normal_like(12, "x", (2, 21, 784))).cuda().requires_grad_(True)
+    y = net(x, None)
+    assert rel_err(y, g["y"]) < 2e-5
+    (y * T(synth.normal_like(13, "cot", (2, 21, 3))).cuda()).sum().backward()
+    assert digest_err(digest(x.grad), g["dx"]) < 5e-5
+    assert rel_err(x.grad[0, :2, :8], g["dx_head"]) < 5e-5
+    for k, p in net.named_parameters():
+        assert digest_err(digest(p.grad), g["g:" + k]) < 5e-5, k
+    # input-gradient replay == autograd (the pose-length term path)
+    ig = net.input_grad(T(synth.normal_like(13, "cot", (2, 21, 3))).cuda())
+    assert rel_err(ig, x.grad) < 1e-6
+
+
+def test_small_modules_standalone(golden):
+    """Attention / FeedForward / PreNorm usable on their own like the reference classes."""
+    from scat_amd.models import vision_transformer as VT
+
+    g = golden("vt")
+    for dim in (784, 392, 196):
+        att = VT.Attention(dim, heads=8, dim_head=64, dropout=0.0)
+        asd = synth.to_torch(synth.vt_state(21, "", dim, 1, 8, 64))
+        att.load_state_dict({"to_qkv.weight": asd["layers.0.0.fn.fn.to_qkv.weight"],
+                             "to_out.0.weight": asd["layers.0.0.fn.fn.to_out.0.weight"],
+                             "to_out.0.bias": asd["layers.0.0.fn.fn.to_out.0.bias"]}, strict=True)
+        att.cuda()
+        xa = T(synth.normal_like(22, f"xa{dim}", (2, 21, dim))).cuda().requires_grad_(True)
+        ya = att(xa)
+        (ya * T(synth.normal_like(23, f"ca{dim}", (2, 21, dim))).cuda()).sum().backward()
+        assert digest_err(digest(ya), g[f"attn{dim}:y"]) < 2e-5
+        assert digest_err(digest(xa.grad), g[f"attn{dim}:dx"]) < 5e-5
+        assert digest_err(digest(att.to_qkv.weight.grad), g[f"attn{dim}:dwqkv"]) < 5e-5
+
+
+def test_vit_golden(golden):
+    from scat_amd.models import vit as V
+
+    g = golden("vit")
+    net = V.Transformer(196, 3, 8, 64, 392, 0.0)
+    net.load_state_dict(synth.to_torch(synth.vit_state(81, "")), strict=True)
+    net.cuda()
+    x = T(synth.normal_like(82, "x", (2, 128, 196))).cuda().requires_grad_(True)
+    y = net(x)
+    assert digest_err(digest(y, 64), g["y"]) < 2e-5
+    (y * T(synth.normal_like(83, "cot", (2, 128, 196))).cuda()).sum().backward()
+    assert digest_err(digest(x.grad, 64), g["dx"]) < 5e-5
+    for k, p in net.named_parameters():
+        assert digest_err(digest(p.grad, 8), g["g:" + k]) < 5e-5, k
+
+
+def test_resnet50_golden(golden):
+    from scat_amd.models import resnet as R
+
+    g = golden("resnet50")
+    net = R.resnet50(pretrained=True, num_classes=512)
+    net.load_state_dict(synth.to_torch(synth.resnet_state(41, "")), strict=True)
+    net.cuda()
+    x = T(synth.images(42, 2)).cuda()
+    for mode in ("train", "eval"):
+        net.train(mode == "train")
+        with torch.no_grad():
+            feat, x1, x2, x3, x4 = net(x)
+        assert rel_err(feat, g[f"{mode}:feat"]) < 5e-5, mode
+        for n, t in (("x1", x1), ("x2", x2), ("x3", x3), ("x4", x4)):
+            assert digest_err(digest(t, 64), g[f"{mode}:{n}"]) < 5e-5, (mode, n)
+            assert rel_err(t.double().sum(dim=(0, 2, 3)), g[f"{mode}:{n}_chsum"]) < 5e-5
+        if mode == "train":
+            assert rel_err(net.bn1.running_mean, g["bn1.running_mean"]) < 1e-5
+            assert rel_err(net.bn1.running_var, g["bn1.running_var"]) < 1e-5
+            assert rel_err(net.layer4[2].bn3.running_var, g["layer4.2.bn3.running_var"]) < 1e-5
+            assert int(net.bn1.num_batches_tracked) == 1
+
+
+def test_encoder_transformer_golden(golden):
+    """G5/G10: forward tuple, loss, every parameter gradient, MPJPE."""
+    from scat_amd.trainer import pose_length_term, scat_loss
+
+    g = golden("encoder")
+    net = make_encoder(51)
+    x, lab = T(synth.images(52, 4)).cuda(), T(synth.labels(53, 4)).cuda()
+    random.seed(3)
+    net.train()
+    pred, fv, pl = net(x)
+    assert rel_err(pred[:, 3:66], g["pred"][:, 3:66]) < 1e-4          # the north_star bar
+    assert rel_err(pred, g["pred"]) < 1e-4
+    assert float(pred[:, 6:9].abs().max()) == 0.0
+    assert not pl.requires_grad
+    assert digest_err(digest(fv, 64), g["fv"]) < 5e-5
+    assert rel_err(fv.double().sum(dim=(0, 2, 3)), g["fv_chsum"]) < 5e-5
+    assert digest_err(digest(pl, 64), g["pl"]) < 1e-4
+    loss, parts = scat_loss(pred, lab)
+    lpl = pose_length_term(pl)
+    total = loss + 10 * lpl
+    ref = g["loss"]
+    assert abs(total.item() - ref[0]) / abs(ref[0]) < 1e-4
+    assert abs(parts[1].item() - ref[1]) / abs(ref[1]) < 1e-4 and abs(parts[2].item() - ref[2]) / abs(ref[2]) < 1e-4
+    assert abs(lpl.item() - ref[3]) / abs(ref[3]) < 1e-3
+    mp = O.mpjpe_mm(pred.detach().cpu(), lab[:, :63].cpu()).item()
+    assert abs(mp - float(g["mpjpe"])) / float(g["mpjpe"]) < 1e-4
+    total.backward()
+    # Gradients of this random-weight network are ill-conditioned in fp32: the reference's own CPU
+    # fp32 gradients sit 2 % (median) to 9 % (worst parameter) from an fp64 evaluation of the same graph
+    # (ReLU-mask / max-pool arg-max flips + train-mode BN at B=4; measured in test_against_oracle_config1).
+    # Against the reference's fp32 goldens the backbone is therefore checked to that noise level, the
+    # head (transformer, regressor, mask token, 1x1 reduction) tightly.
+    named = dict(net.named_parameters())
+    worst_bb, worst_head = ("", 0.0), ("", 0.0)
+    for k, p in named.items():
+        assert p.grad is not None, k
+        e = digest_err(digest(p.grad, 8), g["g:" + k])
+        if k.startswith("main_encoder."):
+            worst_bb = max(worst_bb, (k, e), key=lambda t: t[1])
+        else:
+            worst_head = max(worst_head, (k, e), key=lambda t: t[1])
+    assert worst_head[1] < 5e-4, worst_head
+    assert worst_bb[1] < 0.25, worst_bb
+    for k in ("regressor.weight", "regressor.bias", "mask_token", "conv1x1_channel_reduction.weight",
+              "transformer.layers.2.1.net.2.weight"):
+        assert rel_err(named[k].grad, g["g_full:" + k]) < 5e-4, k
+    # eval mode: masking still active, BN uses running stats
+    net2 = make_encoder(51)
+    net2.eval()
+    random.seed(3)
+    with torch.no_grad():
+        pe, fve, ple = net2(x)
+    assert rel_err(pe, g["eval:pred"]) < 1e-4
+    assert digest_err(digest(fve, 64), g["eval:fv"]) < 5e-5
+
+
+def test_trainstep_golden(golden):
+    """G6: two full train.py iterations (fused loss, flat buckets, fused Adam)."""
+    from scat_amd.trainer import TrainStep
+
+    g = golden("trainstep")
+    net = make_encoder(61)
+    net.train()
+    ts = TrainStep(net, lr=5e-4)
+    random.seed(5)
+    for step in (1, 2):
+        x, lab = T(synth.images(62 + step, 4)).cuda(), T(synth.labels(72 + step, 4)).cuda()
+        loss, parts, lpl, pred = ts(x, lab)
+        ref = g[f"s{step}:loss"]
+        # step 1 is pure forward parity; step 2 runs on Adam-updated weights, and Adam's first update is
+        # +-lr per weight whatever |g| is, so fp32 gradient noise (see above) moves the second loss at 1e-4..1e-3
+        tol = 1e-4 if step == 1 else 3e-3
+        assert abs(loss.item() - ref[0]) / abs(ref[0]) < tol, (step, loss.item(), ref)
+        assert rel_err(pred, g[f"s{step}:pred"]) < (1e-4 if step == 1 else 2e-2)
+        assert rel_err(net.regressor.bias, g[f"s{step}:regressor.bias"]) < 1e-3
+        assert rel_err(net.main_encoder.bn1.running_mean, g[f"s{step}:bn1.running_mean"]) < 1e-4
+        assert digest_err(digest(net.regressor.weight, 32), g[f"s{step}:regressor.weight"]) < 2e-3
+        assert digest_err(digest(net.main_encoder.layer3[0].conv2.weight, 32),
+                          g[f"s{step}:layer3.0.conv2.weight"]) < 5e-3
+    assert int(net.main_encoder.bn1.num_batches_tracked) == int(g["nbt"]) == 2
+
+
+def test_against_oracle_config1():
+    """BASELINE configs[0] geometry (heads 8, iteration 3; B=4 to keep the fp64 CPU pass short): HIP vs the
+    CPU oracle on fresh seeds, forward + backward, no pose-length term / positional encoding / masking
+    (exercises the flag paths).  Gradient criterion: the HIP fp32 gradient must be as close to an fp64
+    evaluation of the same graph as the CPU fp32 oracle is (3x its distance + 1e-4)."""
+    from scat_amd.trainer import scat_loss
+
+    B = 4
+    kw = dict(pl_reg=False, pos_embed=False, mask_rate=0.0)
+    net = make_encoder(7, **kw)
+    net.train()
+    x, lab = T(synth.images(8, B)), T(synth.labels(9, B))
+
+    def oracle(dt):
+        sd = {k: (v.to(dt) if v.dtype == torch.float32 else v)
+              for k, v in synth.to_torch(synth.encoder_transformer_state(7, 8)).items()}
+        params = O.trainable(sd)
+        for p in params.values():
+            p.requires_grad_(True)
+        pr, _ = O.encoder_transformer_forward(sd, T(synth.mean_params(7)).to(dt), x.to(dt), pl_reg=False,
+                                              pos_embed=False, mask_rate=0.0)
+        l, *_ = O.scat_loss(pr, lab.to(dt))
+        l.backward()
+        return pr.detach(), l.item(), {k: p.grad for k, p in params.items() if p.grad is not None}
+
+    p32, l32, g32 = oracle(torch.float32)
+    p64, l64, g64 = oracle(torch.float64)
+    pred, fv = net(x.cuda())
+    assert rel_err(pred[:, 3:66], p32[:, 3:66]) < 1e-4
+    assert rel_err(pred[:, 3:66], p64[:, 3:66]) < 1e-4
+    loss, _ = scat_loss(pred, lab.cuda())
+    loss.backward()
+    assert abs(loss.item() - l32) / abs(l32) < 1e-4
+    named = dict(net.named_parameters())
+    e_hip, e_cpu = [], []
+    for k, gref in g64.items():
+        if k == "mask_token":
+            continue
+        e_hip.append(rel_err(named[k].grad, gref))
+        e_cpu.append(rel_err(g32[k], gref))
+    e_hip, e_cpu = np.array(e_hip), np.array(e_cpu)
+    # two fp32 evaluations land at independent random distances from the fp64 gradient: compare the
+    # distributions, not parameter by parameter
+    assert np.median(e_hip) <= 2 * np.median(e_cpu) + 1e-4, (np.median(e_hip), np.median(e_cpu))
+    assert e_hip.max() <= 3 * e_cpu.max() + 1e-4, (e_hip.max(), e_cpu.max())
+    assert np.mean(e_hip) <= 2 * np.mean(e_cpu) + 1e-4, (np.mean(e_hip), np.mean(e_cpu))
+    assert named["mask_token"].grad is None or float(named["mask_token"].grad.abs().max()) == 0.0
