@@ -1,0 +1,23 @@
+#pragma once
+#include "gemm_engine.h"
+
+namespace scat {
+
+static inline int check_geom(const char* who, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride,
+                             int pad, int* OH, int* OW) {
+    SCAT_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, SCAT_E_SHAPE, "%s: non-positive dimension", who);
+    SCAT_REQUIRE(KH == KW && (KH == 1 || KH == 3 || KH == 7), SCAT_E_SHAPE, "%s: kernel %dx%d unsupported", who, KH,
+                 KW);
+    SCAT_REQUIRE(stride == 1 || stride == 2, SCAT_E_SHAPE, "%s: stride %d unsupported", who, stride);
+    SCAT_REQUIRE(pad >= 0 && pad < KH + (KH == 1), SCAT_E_SHAPE, "%s: pad %d unsupported", who, pad);
+    *OH = (H + 2 * pad - KH) / stride + 1;
+    *OW = (W + 2 * pad - KW) / stride + 1;
+    SCAT_REQUIRE(*OH > 0 && *OW > 0, SCAT_E_SHAPE, "%s: empty output", who);
+    // byte offsets are 32-bit buffer-load offsets: every tensor must stay below 2 GiB
+    SCAT_REQUIRE(fits_i32((int64_t)B * Cin * H * W * 4) && fits_i32((int64_t)B * Cout * *OH * *OW * 4) &&
+                     fits_i32((int64_t)Cout * Cin * KH * KW * 4),
+                 SCAT_E_SHAPE, "%s: tensor exceeds 2 GiB", who);
+    return SCAT_OK;
+}
+
+}  // namespace scat

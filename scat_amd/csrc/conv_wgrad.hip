@@ -1,0 +1,104 @@
+// Convolution weight-gradient: dW[Cout][Cin*KH*KW] = dY[Cout][pixels] * im2col(X)[pixels][Cin*KH*KW],
+// contraction over B*OH*OW pixels, deterministic two-stage split-K (slabs + fixed-order sum).
+#include "conv_common.h"
+
+namespace scat {
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int splits,
+                                     int accumulate) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        float s = accumulate ? out[e] : 0.f;
+        for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * n + e];
+        out[e] = s;
+    }
+}
+
+static int wgrad_splits(int M, int N, int K, int bm, int bn) {
+    int tiles = cdiv(M, bm) * cdiv(N, bn);
+    int s = cdiv(1024, tiles);                       // aim for ~4 workgroups per CU
+    int smax = K / 512 > 0 ? K / 512 : 1;            // keep >= 512 contraction steps per slice
+    if (s > smax) s = smax;
+    if (s > 256) s = 256;
+    return s < 1 ? 1 : s;
+}
+
+struct WgradPlan {
+    int M, N, K, bm, bn, splits;
+};
+static WgradPlan wgrad_plan(int B, int Cin, int Cout, int KK, int OH, int OW) {
+    WgradPlan p;
+    p.M = Cout;
+    p.N = Cin * KK;
+    p.K = B * OH * OW;
+    p.bm = Cout <= 64 ? 64 : 128;
+    p.bn = 64;
+    p.splits = wgrad_splits(p.M, p.N, p.K, p.bm, p.bn);
+    return p;
+}
+
+template <int KH, int KW, bool AV4, bool BV4>
+static void wgrad_gemm(const WgradPlan& p, const GatherDesc& da, const GatherDesc& db, const OutDesc& dc,
+                       hipStream_t st) {
+    set_kernel_label("wgrad%dx%d_%dx64x32%s%s_split%d", KH, KW, p.bm, AV4 ? "_a4" : "", BV4 ? "_b4" : "", p.splits);
+    if (p.bm == 64)
+        launch_gemm<GatherLoader<64, 32, 1, 1, false, true, AV4>, GatherLoader<64, 32, KH, KW, false, true, BV4>, 64,
+                    64, 32, 2, 2>(da, db, dc, p.M, p.N, p.K, p.splits, st);
+    else
+        launch_gemm<GatherLoader<128, 32, 1, 1, false, true, AV4>, GatherLoader<64, 32, KH, KW, false, true, BV4>,
+                    128, 64, 32, 2, 2>(da, db, dc, p.M, p.N, p.K, p.splits, st);
+}
+
+}  // namespace scat
+
+using namespace scat;
+
+extern "C" int64_t scat_conv2d_wgrad_ws(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
+    int OH, OW;
+    if (check_geom("scat_conv2d_wgrad_ws", B, Cin, H, W, Cout, KH, KW, stride, pad, &OH, &OW)) return -1;
+    WgradPlan p = wgrad_plan(B, Cin, Cout, KH * KW, OH, OW);
+    return p.splits > 1 ? (int64_t)p.splits * p.M * p.N * sizeof(float) : 0;
+}
+
+extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout,
+                                 int KH, int KW, int stride, int pad, const float* in_scale, const float* in_shift,
+                                 int in_relu, void* ws, int64_t ws_bytes, void* stream) {
+    int OH, OW;
+    if (int e = check_geom("scat_conv2d_wgrad", B, Cin, H, W, Cout, KH, KW, stride, pad, &OH, &OW)) return e;
+    SCAT_REQUIRE(dy && x && dw, SCAT_E_ARG, "scat_conv2d_wgrad: null pointer");
+    SCAT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), SCAT_E_ARG, "scat_conv2d_wgrad: scale/shift pair");
+    WgradPlan p = wgrad_plan(B, Cin, Cout, KH * KW, OH, OW);
+    int64_t need = p.splits > 1 ? (int64_t)p.splits * p.M * p.N * sizeof(float) : 0;
+    SCAT_REQUIRE(ws_bytes >= need && (need == 0 || ws), SCAT_E_WORKSPACE,
+                 "scat_conv2d_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    const int npix = B * OH * OW;
+    // A: dy as [Cout][pixel]; B: x through the forward conv arithmetic as [pixel][(ci,kh,kw)]
+    GatherDesc da{dy, nullptr, nullptr, 0, Cout, OH, OW, OH, OW, 1, 0, 0, npix, Cout, FastDiv::make(OH * OW),
+                  FastDiv::make(OW), (int64_t)B * Cout * OH * OW};
+    GatherDesc db{x, in_scale, in_shift, in_relu, Cin, H, W, OH, OW, stride, 1, -pad, npix, Cin * KH * KW,
+                  FastDiv::make(OH * OW), FastDiv::make(OW), (int64_t)B * Cin * H * W};
+    OutDesc dc{};
+    dc.p = p.splits > 1 ? (float*)ws : dw;
+    dc.mode = 0; dc.si = p.N; dc.sj = 1; dc.sz = (int64_t)p.M * p.N; dc.I = p.M; dc.J = p.N;
+    hipStream_t st = (hipStream_t)stream;
+    const bool av4 = (OH * OW) % 4 == 0 && ((uintptr_t)dy & 15) == 0;
+    const bool bv4 = KH == 1 && stride == 1 && pad == 0 && (H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    if (KH == 1) {
+        if (av4 && bv4) wgrad_gemm<1, 1, true, true>(p, da, db, dc, st);
+        else if (av4) wgrad_gemm<1, 1, true, false>(p, da, db, dc, st);
+        else wgrad_gemm<1, 1, false, false>(p, da, db, dc, st);
+    } else if (KH == 3) {
+        if (av4) wgrad_gemm<3, 3, true, false>(p, da, db, dc, st);
+        else wgrad_gemm<3, 3, false, false>(p, da, db, dc, st);
+    } else {
+        if (av4) wgrad_gemm<7, 7, true, false>(p, da, db, dc, st);
+        else wgrad_gemm<7, 7, false, false>(p, da, db, dc, st);
+    }
+    SCAT_LAUNCH_CHECK("scat_conv2d_wgrad");
+    if (p.splits > 1) {
+        int64_t n = (int64_t)p.M * p.N;
+        int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, n, p.splits, 0);
+        SCAT_LAUNCH_CHECK("scat_conv2d_wgrad(reduce)");
+    }
+    return SCAT_OK;
+}

@@ -36,6 +36,7 @@ struct MatDesc {          // elem(i,k) = p[z*sz + i*si + k*sk]
     const float* p;
     int64_t si, sk, sz;
     int I, K;
+    int64_t n;            // floats addressable from p + z*sz (buffer bounds)
 };
 
 struct GatherDesc {       // elem(pix, ct) of an NCHW tensor through conv arithmetic
@@ -49,6 +50,7 @@ struct GatherDesc {       // elem(pix, ct) of an NCHW tensor through conv arithm
     int npix;             // Nimg*PH*PW
     int nct;              // C*KH*KW
     FastDiv dPHW, dPW;
+    int64_t n;            // floats in the source tensor (buffer bounds)
 };
 
 struct OutDesc {
@@ -64,58 +66,95 @@ struct OutDesc {
 };
 
 // ---------------------------------------------------------------- loaders
+//
+// All global reads are raw buffer loads through a wave-uniform SRSRC descriptor: an element that
+// must read as zero (tile edge, conv padding, wrong stride-2 parity) gets voffset = 2^31, which the
+// hardware bounds check turns into 0 — no exec-mask branches, no per-load s_waitcnt, every load of a
+// K-step is in flight together.  The fused BatchNorm+ReLU transform is applied when the registers are
+// written to LDS (after the MFMAs of the previous K-step), masked so padding stays zero.
 
-template <int BI, int BK, bool KFAST>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int OOB = (int)0x80000000;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, int64_t nfloats) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(nfloats * 4), 0x00020000);
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// VEC = 1: one float per load.  VEC = 4 (KFAST only): 16-B loads along k; needs sk == 1, K % 4 == 0,
+// 16-B aligned rows (host checks).
+template <int BI, int BK, bool KFAST, int VEC = 1>
 struct MatLoader {
     static constexpr int NE = BI * BK / NT;
+    static constexpr int NV = NE / VEC;
+    static constexpr int TPR = BK / VEC;          // threads per row along k (KFAST)
     using Desc = MatDesc;
     float v[NE];
     int i_t, k_t;
-    const float* base;
+    __amdgpu_buffer_rsrc_t rs;
 
     __device__ __forceinline__ void init(const MatDesc& d, int i0, int z) {
         const int tid = threadIdx.x;
-        if (KFAST) { k_t = tid % BK; i_t = tid / BK; }
+        if (KFAST) { k_t = (tid % TPR) * VEC; i_t = tid / TPR; }
         else       { i_t = tid % BI; k_t = tid / BI; }
-        base = d.p + (int64_t)z * d.sz;
+        rs = make_rsrc(d.p + (int64_t)z * d.sz, d.n);
         i_t += i0;
     }
     __device__ __forceinline__ void load(const MatDesc& d, int k0, int kend) {
 #pragma unroll
-        for (int r = 0; r < NE; ++r) {
-            int i = i_t + (KFAST ? r * (NT / BK) : 0);
+        for (int r = 0; r < NV; ++r) {
+            int i = i_t + (KFAST ? r * (NT / TPR) : 0);
             int k = k0 + k_t + (KFAST ? 0 : r * (NT / BI));
             bool ok = (i < d.I) && (k < kend);
-            v[r] = ok ? base[(int64_t)i * d.si + (int64_t)k * d.sk] : 0.f;
+            int off = ok ? (i * (int)d.si + k * (int)d.sk) * 4 : OOB;
+            if (VEC == 4) {
+                float4 t = bload4(rs, off);
+                v[4 * r] = t.x; v[4 * r + 1] = t.y; v[4 * r + 2] = t.z; v[4 * r + 3] = t.w;
+            } else {
+                v[r] = bload(rs, off);
+            }
         }
     }
-    __device__ __forceinline__ void store(float* lds, int i0) const {
+    __device__ __forceinline__ void store(const MatDesc&, float* lds) const {
         const int tid = threadIdx.x;
 #pragma unroll
-        for (int r = 0; r < NE; ++r) {
-            int il = KFAST ? tid / BK + r * (NT / BK) : tid % BI;
-            int kl = KFAST ? tid % BK : tid / BI + r * (NT / BI);
-            lds[kl * (BI + LPAD) + il] = v[r];
+        for (int r = 0; r < NV; ++r) {
+            int il = KFAST ? tid / TPR + r * (NT / TPR) : tid % BI;
+            int kl = KFAST ? (tid % TPR) * VEC : tid / BI + r * (NT / BI);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) lds[(kl + q) * (BI + LPAD) + il] = v[VEC * r + q];
         }
     }
 };
 
-// Conv-arithmetic loader. KH,KW compile-time so tap decode is mul-shift. D2 = divisor 2
-// (data-gradient of a stride-2 conv: only taps of matching parity contribute).
-template <int BI, int BK, int KH, int KW, bool D2, bool PIXK>
+// Conv-arithmetic loader. KH,KW compile-time so tap decode is mul-shift. D2 = divisor 2 (data-gradient
+// of a stride-2 conv: only taps of matching parity contribute).  PIXK: the pixel index is the
+// contraction index (weight gradient).  V4: 16-B loads along 4 consecutive pixels — only for
+// KH=KW=1, stride 1, no padding, (PH*PW) % 4 == 0.
+template <int BI, int BK, int KH, int KW, bool D2, bool PIXK, bool V4 = false>
 struct GatherLoader {
     static constexpr int KK = KH * KW;
     static constexpr int NE = BI * BK / NT;
+    static constexpr int NV = V4 ? NE / 4 : NE;
+    static_assert(!V4 || (KK == 1 && !D2), "V4 is the 1x1 stride-1 path");
     using Desc = GatherDesc;
     float v[NE];
-    // pixel-side state (per tile when !PIXK, per K-step when PIXK)
+    unsigned okbits;
     int pixoff;
     uint64_t mask;
-    // ct-side state when PIXK (fixed per tile)
-    int ctoff[PIXK ? NE : 1];
-    int ctc[PIXK ? NE : 1];
-    int cttap[PIXK ? NE : 1];   // -1 = out of range
-    int idx0;                   // first i (pixel when !PIXK, ct when PIXK)
+    // PIXK: ct-side state fixed per tile (offset, tap, fused-transform constants)
+    int ctoff[PIXK ? NV : 1];
+    int cttap[PIXK ? NV : 1];
+    float csc[PIXK ? NV : 1], csh[PIXK ? NV : 1];
+    // !PIXK: per-K-step channel of each element row, wave-uniform
+    float rsc[PIXK ? 1 : NV], rsh[PIXK ? 1 : NV];
+    __amdgpu_buffer_rsrc_t rs;
 
     static __device__ __forceinline__ int tap_off(const GatherDesc& d, int tap) {
         int kh = tap / KW, kw = tap - kh * KW;
@@ -151,62 +190,94 @@ struct GatherLoader {
         pixoff = (int)n * d.C * d.H * d.W + (D2 ? ((ty0 >> 1) * d.W + (tx0 >> 1)) : (ty0 * d.W + tx0));
     }
 
+    // thread -> (pixel-side index, ct-side index) inside the tile, element r
+    static constexpr int PV = V4 ? 4 : 1;                                   // pixels per load
+    static constexpr int PT = (PIXK ? BK : BI) / PV;                        // threads along the pixel dim
+    __device__ __forceinline__ int pix_l() const { return (threadIdx.x % PT) * PV; }
+    __device__ __forceinline__ int ct_l(int r) const { return threadIdx.x / PT + r * (NT / PT); }
+
     __device__ __forceinline__ void init(const GatherDesc& d, int i0, int /*z*/) {
-        const int tid = threadIdx.x;
-        idx0 = i0;
+        rs = make_rsrc(d.p, d.n);
+        okbits = 0;
         if (!PIXK) {
-            decode_pix(d, i0 + tid % BI);
+            decode_pix(d, i0 + pix_l());
         } else {
 #pragma unroll
-            for (int r = 0; r < NE; ++r) {
-                int ct = i0 + tid / BK + r * (NT / BK);
+            for (int r = 0; r < NV; ++r) {
+                int ct = i0 + ct_l(r);
                 int c = ct / KK, tap = ct - c * KK;
                 bool ok = ct < d.nct;
-                ctc[r] = ok ? c : 0;
                 cttap[r] = ok ? tap : -1;
                 ctoff[r] = c * d.H * d.W + tap_off(d, tap);
+                csc[r] = (ok && d.scale) ? d.scale[c] : 1.f;
+                csh[r] = (ok && d.scale) ? d.shift[c] : 0.f;
             }
         }
-    }
-
-    __device__ __forceinline__ float fetch(const GatherDesc& d, int off, int c, bool ok) const {
-        float x = 0.f;
-        if (ok) {
-            x = d.p[off];
-            if (d.scale) x = fmaf(x, d.scale[c], d.shift[c]);
-            if (d.relu) x = fmaxf(x, 0.f);
-        }
-        return x;
     }
 
     __device__ __forceinline__ void load(const GatherDesc& d, int k0, int kend) {
-        const int tid = threadIdx.x;
+        okbits = 0;
         if (!PIXK) {
 #pragma unroll
-            for (int r = 0; r < NE; ++r) {
-                int ct = k0 + tid / BI + r * (NT / BI);
+            for (int r = 0; r < NV; ++r) {
+                // with >= 64 threads along the pixel dim the ct row is the same for the whole wavefront:
+                // make that visible so the tap decode and the fused-transform constants go scalar
+                int ct = k0 + (PT >= 64 ? __builtin_amdgcn_readfirstlane(ct_l(r)) : ct_l(r));
                 int c = ct / KK, tap = ct - c * KK;
                 bool ok = (ct < kend) && ((mask >> tap) & 1ull);
-                v[r] = fetch(d, pixoff + c * d.H * d.W + tap_off(d, tap), c, ok);
+                int off = ok ? (pixoff + c * d.H * d.W + tap_off(d, tap)) * 4 : OOB;
+                if (V4) {
+                    float4 t = bload4(rs, off);
+                    v[4 * r] = t.x; v[4 * r + 1] = t.y; v[4 * r + 2] = t.z; v[4 * r + 3] = t.w;
+                } else {
+                    v[r] = bload(rs, off);
+                }
+                okbits |= (ok ? 1u : 0u) << r;
+                if (d.scale) {
+                    int cc = ct < kend ? c : 0;
+                    rsc[r] = d.scale[cc];
+                    rsh[r] = d.shift[cc];
+                }
             }
         } else {
-            int pix = k0 + tid % BK;
+            int pix = k0 + pix_l();
             decode_pix(d, pix < kend ? pix : d.npix);
 #pragma unroll
-            for (int r = 0; r < NE; ++r) {
+            for (int r = 0; r < NV; ++r) {
                 bool ok = (cttap[r] >= 0) && ((mask >> (cttap[r] & 63)) & 1ull);
-                v[r] = fetch(d, pixoff + ctoff[r], ctc[r], ok);
+                int off = ok ? (pixoff + ctoff[r]) * 4 : OOB;
+                if (V4) {
+                    float4 t = bload4(rs, off);
+                    v[4 * r] = t.x; v[4 * r + 1] = t.y; v[4 * r + 2] = t.z; v[4 * r + 3] = t.w;
+                } else {
+                    v[r] = bload(rs, off);
+                }
+                okbits |= (ok ? 1u : 0u) << r;
             }
         }
     }
 
-    __device__ __forceinline__ void store(float* lds, int /*i0*/) const {
-        const int tid = threadIdx.x;
+    __device__ __forceinline__ void store(const GatherDesc& d, float* lds) const {
 #pragma unroll
-        for (int r = 0; r < NE; ++r) {
-            int il = PIXK ? tid / BK + r * (NT / BK) : tid % BI;
-            int kl = PIXK ? tid % BK : tid / BI + r * (NT / BI);
-            lds[kl * (BI + LPAD) + il] = v[r];
+        for (int r = 0; r < NV; ++r) {
+            const bool ok = (okbits >> r) & 1u;
+            float t[PV];
+#pragma unroll
+            for (int q = 0; q < PV; ++q) {
+                float x = v[PV * r + q];
+                if (d.scale) x = fmaf(x, PIXK ? csc[r] : rsc[r], PIXK ? csh[r] : rsh[r]);
+                if (d.relu) x = fmaxf(x, 0.f);
+                t[q] = ok ? x : 0.f;
+            }
+            const int pl = pix_l(), cl = ct_l(r);
+            if (!PIXK) {          // tile[k = ct][i = pixel]: pixels contiguous
+                float* dst = lds + cl * (BI + LPAD) + pl;
+                if (V4) *(float4*)dst = make_float4(t[0], t[1], t[2], t[3]);
+                else dst[0] = t[0];
+            } else {              // tile[k = pixel][i = ct]
+#pragma unroll
+                for (int q = 0; q < PV; ++q) lds[(pl + q) * (BI + LPAD) + cl] = t[q];
+            }
         }
     }
 };
@@ -258,8 +329,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename
     if (nk > 0) {
         la.load(da, kbeg, kend);
         lb.load(db, kbeg, kend);
-        la.store(As(0), i0);
-        lb.store(Bs(0), j0);
+        la.store(da, As(0));
+        lb.store(db, Bs(0));
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -284,8 +355,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
         if (kt + 1 < nk) {
-            la.store(As(cur ^ 1), i0);
-            lb.store(Bs(cur ^ 1), j0);
+            la.store(da, As(cur ^ 1));
+            lb.store(db, Bs(cur ^ 1));
         }
         __syncthreads();
     }

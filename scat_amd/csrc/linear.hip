@@ -24,16 +24,16 @@ static GemmPlan gemm_plan(int M, int N, int K) {
     return p;
 }
 
-template <bool AK, bool BK_>
+template <bool AK, bool BK_, int AV, int BV>
 static void gemm_dispatch(const GemmPlan& p, const MatDesc& da, const MatDesc& db, const OutDesc& dc, int M, int N,
                           int K, hipStream_t st) {
-    set_kernel_label("gemm_%c%c_%dx64x16_split%d", AK ? 'k' : 'i', BK_ ? 'k' : 'j', p.bm, p.splits);
+    set_kernel_label("gemm_%c%d%c%d_%dx64x16_split%d", AK ? 'k' : 'i', AV, BK_ ? 'k' : 'j', BV, p.bm, p.splits);
     if (p.bm == 128)
-        launch_gemm<MatLoader<128, 16, AK>, MatLoader<64, 16, BK_>, 128, 64, 16, 2, 2>(da, db, dc, M, N, K, p.splits,
-                                                                                        st);
+        launch_gemm<MatLoader<128, 16, AK, AV>, MatLoader<64, 16, BK_, BV>, 128, 64, 16, 2, 2>(da, db, dc, M, N, K,
+                                                                                                p.splits, st);
     else
-        launch_gemm<MatLoader<64, 16, AK>, MatLoader<64, 16, BK_>, 64, 64, 16, 2, 2>(da, db, dc, M, N, K, p.splits,
-                                                                                      st);
+        launch_gemm<MatLoader<64, 16, AK, AV>, MatLoader<64, 16, BK_, BV>, 64, 64, 16, 2, 2>(da, db, dc, M, N, K,
+                                                                                              p.splits, st);
 }
 
 __global__ void splitk_reduce_bias_kernel(const float* __restrict__ slab, float* __restrict__ c, int64_t c_si,
@@ -72,8 +72,11 @@ extern "C" int scat_gemm(const float* a, int64_t a_si, int64_t a_sk, const float
     GemmPlan p = gemm_plan(M, N, K);
     int64_t need = p.splits > 1 ? (int64_t)p.splits * M * N * sizeof(float) : 0;
     if (need > ws_bytes || (need && !ws)) { p.splits = 1; need = 0; }   // no workspace: single pass
-    MatDesc da{a, a_si, a_sk, 0, M, K};
-    MatDesc db{b, b_sj, b_sk, 0, N, K};
+    SCAT_REQUIRE(fits_i32(((int64_t)(M - 1) * a_si + (int64_t)(K - 1) * a_sk + 1) * 4) &&
+                     fits_i32(((int64_t)(N - 1) * b_sj + (int64_t)(K - 1) * b_sk + 1) * 4),
+                 SCAT_E_SHAPE, "scat_gemm: operand exceeds 2 GiB");
+    MatDesc da{a, a_si, a_sk, 0, M, K, (int64_t)(M - 1) * a_si + (int64_t)(K - 1) * a_sk + 1};
+    MatDesc db{b, b_sj, b_sk, 0, N, K, (int64_t)(N - 1) * b_sj + (int64_t)(K - 1) * b_sk + 1};
     OutDesc dc{};
     hipStream_t st = (hipStream_t)stream;
     if (p.splits > 1) {
@@ -83,10 +86,21 @@ extern "C" int scat_gemm(const float* a, int64_t a_si, int64_t a_sk, const float
         dc.bias = bias; dc.bias_mode = bias_mode; dc.accumulate = accumulate;
     }
     const bool ak = (a_sk == 1), bk = (b_sk == 1);
-    if (ak && bk) gemm_dispatch<true, true>(p, da, db, dc, M, N, K, st);
-    else if (ak) gemm_dispatch<true, false>(p, da, db, dc, M, N, K, st);
-    else if (bk) gemm_dispatch<false, true>(p, da, db, dc, M, N, K, st);
-    else gemm_dispatch<false, false>(p, da, db, dc, M, N, K, st);
+    // 16-B loads along k where the contraction dim is contiguous, a multiple of 4, and rows stay 16-B aligned
+    const bool av = ak && K % 4 == 0 && a_si % 4 == 0 && ((uintptr_t)a & 15) == 0;
+    const bool bv = bk && K % 4 == 0 && b_sj % 4 == 0 && ((uintptr_t)b & 15) == 0;
+    if (ak && bk) {
+        if (av && bv) gemm_dispatch<true, true, 4, 4>(p, da, db, dc, M, N, K, st);
+        else gemm_dispatch<true, true, 1, 1>(p, da, db, dc, M, N, K, st);
+    } else if (ak) {
+        if (av) gemm_dispatch<true, false, 4, 1>(p, da, db, dc, M, N, K, st);
+        else gemm_dispatch<true, false, 1, 1>(p, da, db, dc, M, N, K, st);
+    } else if (bk) {
+        if (bv) gemm_dispatch<false, true, 1, 4>(p, da, db, dc, M, N, K, st);
+        else gemm_dispatch<false, true, 1, 1>(p, da, db, dc, M, N, K, st);
+    } else {
+        gemm_dispatch<false, false, 1, 1>(p, da, db, dc, M, N, K, st);
+    }
     SCAT_LAUNCH_CHECK("scat_gemm");
     if (p.splits > 1) {
         int64_t n = (int64_t)M * N;

@@ -47,9 +47,11 @@ class GradBuckets:
         groups: Dict[str, List] = OrderedDict((b, []) for b in order)
         for n, p in named:
             groups[_bucket_of(n)].append((n, p))
-        total = sum(p.numel() for _, p in named)
+        ALIGN = 64   # floats (256 B): every parameter view stays 16-B aligned for the kernels' dwordx4 loads
+        pad = lambda k: (k + ALIGN - 1) // ALIGN * ALIGN
+        total = sum(pad(p.numel()) for _, p in named)
         dev = named[0][1].device
-        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)   # padding stays 0 under Adam
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.ranges: Dict[str, tuple] = {}
         self.slot: Dict[torch.nn.Parameter, tuple] = {}
@@ -63,7 +65,7 @@ class GradBuckets:
                 p.data = self.flat_param[off:off + k].view_as(p)   # parameters now alias the flat buffer
                 self.slot[p] = (off, k)
                 self.names[p] = n
-                off += k
+                off += pad(k)
             self.ranges[b] = (start, off)
         self.head_params = [p for _, p in groups["head"]]
         self.pg = process_group

@@ -191,7 +191,7 @@ def test_trainstep_golden(golden):
         assert rel_err(net.main_encoder.bn1.running_mean, g[f"s{step}:bn1.running_mean"]) < 1e-4
         assert digest_err(digest(net.regressor.weight, 32), g[f"s{step}:regressor.weight"]) < 2e-3
         assert digest_err(digest(net.main_encoder.layer3[0].conv2.weight, 32),
-                          g[f"s{step}:layer3.0.conv2.weight"]) < 5e-3
+                          g[f"s{step}:layer3.0.conv2.weight"]) < (1e-4 if step == 1 else 5e-2)
     assert int(net.main_encoder.bn1.num_batches_tracked) == int(g["nbt"]) == 2
 
 
