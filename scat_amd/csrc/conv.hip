@@ -18,46 +18,66 @@ static Cfg pick_cfg(int M, int N) {
 }
 
 // forward / data-gradient share one kernel family: A = weights (K contiguous), B = gather, pixel = column
-template <int KH, int KW, bool D2, int AV, bool BV4>
+template <int KH, int KW, bool D2, int AV, bool BV4, bool TF>
 static void conv_gemm_cfg(Cfg cfg, const MatDesc& da, const GatherDesc& db, const OutDesc& dc, int M, int N, int K,
                           hipStream_t st) {
     static const char* const names[] = {"128x128", "128x64", "64x128", "64x64"};
-    set_kernel_label("conv%dx%d%s_%sx16_a%d%s", KH, KW, D2 ? "_d2" : "", names[cfg], AV, BV4 ? "_b4" : "");
+    set_kernel_label("conv%dx%d%s_%sx16_a%d%s%s", KH, KW, D2 ? "_d2" : "", names[cfg], AV, BV4 ? "_b4" : "",
+                     TF ? "_tf" : "");
+    const int tune = tuning();
+    if (tune && AV == 4 && cfg == C128x128) {   // experiment: stagger in 100 MHz ticks per slot = tune * K/64
+        set_kernel_label("conv%dx%d%s_%s_a%d%s_tune%d", KH, KW, D2 ? "_d2" : "", names[cfg], AV, BV4 ? "_b4" : "", tune);
+        launch_gemm<MatLoader<128, 16, true, AV>, GatherLoader<128, 16, KH, KW, D2, false, BV4, TF>, 128, 128, 16, 2,
+                    2>(da, db, dc, M, N, K, 1, st, tune * (K / 16));
+        return;
+    }
     switch (cfg) {
         case C128x128:
-            launch_gemm<MatLoader<128, 16, true, AV>, GatherLoader<128, 16, KH, KW, D2, false, BV4>, 128, 128, 16, 2,
-                        2>(da, db, dc, M, N, K, 1, st);
+            launch_gemm<MatLoader<128, 16, true, AV>, GatherLoader<128, 16, KH, KW, D2, false, BV4, TF>, 128, 128, 16,
+                        2, 2>(da, db, dc, M, N, K, 1, st);
             break;
         case C128x64:
-            launch_gemm<MatLoader<128, 16, true, AV>, GatherLoader<64, 16, KH, KW, D2, false, BV4>, 128, 64, 16, 2,
+            launch_gemm<MatLoader<128, 16, true, AV>, GatherLoader<64, 16, KH, KW, D2, false, BV4, TF>, 128, 64, 16, 2,
                         2>(da, db, dc, M, N, K, 1, st);
             break;
         case C64x128:
-            launch_gemm<MatLoader<64, 16, true, AV>, GatherLoader<128, 16, KH, KW, D2, false, BV4>, 64, 128, 16, 2,
+            launch_gemm<MatLoader<64, 16, true, AV>, GatherLoader<128, 16, KH, KW, D2, false, BV4, TF>, 64, 128, 16, 2,
                         2>(da, db, dc, M, N, K, 1, st);
             break;
         default:
-            launch_gemm<MatLoader<64, 16, true, AV>, GatherLoader<64, 16, KH, KW, D2, false, BV4>, 64, 64, 16, 2, 2>(
-                da, db, dc, M, N, K, 1, st);
+            launch_gemm<MatLoader<64, 16, true, AV>, GatherLoader<64, 16, KH, KW, D2, false, BV4, TF>, 64, 64, 16, 2,
+                        2>(da, db, dc, M, N, K, 1, st);
     }
+}
+
+template <int KH, int KW, bool D2, bool TF>
+static void conv_gemm_tf(const MatDesc& da, const GatherDesc& db, const OutDesc& dc, int M, int N, int K, bool bv4,
+                         hipStream_t st) {
+    const bool av4 = (K % 4 == 0) && (((uintptr_t)da.p & 15) == 0);
+    if (!av4) {   // odd contraction length (the 7x7 stem: K = 147): scalar weight loads
+        conv_gemm_cfg<KH, KW, D2, 1, false, TF>(KH == 7 ? pick_cfg(M, N) : C64x64, da, db, dc, M, N, K, st);
+        return;
+    }
+    if constexpr (KH == 1 && !D2) {
+        if (bv4) {
+            conv_gemm_cfg<1, 1, false, 4, true, TF>(pick_cfg(M, N), da, db, dc, M, N, K, st);
+            return;
+        }
+    }
+    if constexpr (KH != 7) conv_gemm_cfg<KH, KW, D2, 4, false, TF>(pick_cfg(M, N), da, db, dc, M, N, K, st);
+    else conv_gemm_cfg<KH, KW, D2, 1, false, TF>(pick_cfg(M, N), da, db, dc, M, N, K, st);
 }
 
 template <int KH, int KW, bool D2>
 static void conv_gemm(const MatDesc& da, const GatherDesc& db, const OutDesc& dc, int M, int N, int K, bool bv4,
                       hipStream_t st) {
-    const bool av4 = (K % 4 == 0) && (((uintptr_t)da.p & 15) == 0);
-    if (!av4) {   // odd contraction length (the 7x7 stem: K = 147): scalar weight loads
-        conv_gemm_cfg<KH, KW, D2, 1, false>(KH == 7 ? pick_cfg(M, N) : C64x64, da, db, dc, M, N, K, st);
-        return;
-    }
-    if constexpr (KH == 1 && !D2) {
-        if (bv4) {
-            conv_gemm_cfg<1, 1, false, 4, true>(pick_cfg(M, N), da, db, dc, M, N, K, st);
+    if constexpr (KH != 7 && !D2) {   // the fused BatchNorm+ReLU input transform exists on forward 1x1 / 3x3 only
+        if (db.scale) {
+            conv_gemm_tf<KH, KW, D2, true>(da, db, dc, M, N, K, bv4, st);
             return;
         }
     }
-    if constexpr (KH != 7) conv_gemm_cfg<KH, KW, D2, 4, false>(pick_cfg(M, N), da, db, dc, M, N, K, st);
-    else conv_gemm_cfg<KH, KW, D2, 1, false>(pick_cfg(M, N), da, db, dc, M, N, K, st);
+    conv_gemm_tf<KH, KW, D2, false>(da, db, dc, M, N, K, bv4, st);
 }
 
 __global__ void wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int KK) {
@@ -82,13 +102,15 @@ extern "C" int scat_conv2d_fwd(const float* x, const float* w, const float* bias
     if (int e = check_geom("scat_conv2d_fwd", B, Cin, H, W, Cout, KH, KW, stride, pad, &OH, &OW)) return e;
     SCAT_REQUIRE(x && w && y, SCAT_E_ARG, "scat_conv2d_fwd: null pointer");
     SCAT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), SCAT_E_ARG, "scat_conv2d_fwd: scale/shift pair");
+    SCAT_REQUIRE(!(in_scale && KH == 7), SCAT_E_SHAPE, "scat_conv2d_fwd: fused input transform not built for 7x7");
+    if (!in_scale) in_relu = 0;
     const int KK = KH * KW, K = Cin * KK, N = B * OH * OW;
     MatDesc da{w, K, 1, 0, Cout, K, (int64_t)Cout * K};
     GatherDesc db{x, in_scale, in_shift, in_relu, Cin, H, W, OH, OW, stride, 1, -pad, N, K,
                   FastDiv::make(OH * OW), FastDiv::make(OW), (int64_t)B * Cin * H * W};
     OutDesc dc{};
     dc.p = y; dc.mode = 1; dc.I = Cout; dc.J = N; dc.C = Cout; dc.HW = OH * OW; dc.dHW = FastDiv::make(OH * OW);
-    dc.bias = bias; dc.bias_mode = bias ? 1 : 0; dc.accumulate = 0;
+    dc.bias = bias; dc.bias_mode = bias ? 1 : 0; dc.accumulate = 0; dc.n = (int64_t)B * Cout * OH * OW;
     hipStream_t st = (hipStream_t)stream;
     const bool bv4 = KH == 1 && stride == 1 && pad == 0 && (H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0;
     if (KH == 1) conv_gemm<1, 1, false>(da, db, dc, Cout, N, K, bv4, st);
@@ -120,7 +142,7 @@ extern "C" int scat_conv2d_dgrad(const float* dy, const float* wt, float* dx, in
                   FastDiv::make(W), (int64_t)B * Cout * OH * OW};
     OutDesc dc{};
     dc.p = dx; dc.mode = 1; dc.I = Cin; dc.J = N; dc.C = Cin; dc.HW = H * W; dc.dHW = FastDiv::make(H * W);
-    dc.accumulate = accumulate;
+    dc.accumulate = accumulate; dc.n = (int64_t)B * Cin * H * W;
     hipStream_t st = (hipStream_t)stream;
     const bool bv4 = KH == 1 && stride == 1 && pad == 0 && (H * W) % 4 == 0 && ((uintptr_t)dy & 15) == 0;
     if (stride == 1) {

@@ -36,16 +36,31 @@ static WgradPlan wgrad_plan(int B, int Cin, int Cout, int KK, int OH, int OW) {
     return p;
 }
 
+template <int KH, int KW, bool AV4, bool BV4, bool TF>
+static void wgrad_gemm_tf(const WgradPlan& p, const GatherDesc& da, const GatherDesc& db, const OutDesc& dc,
+                          hipStream_t st) {
+    set_kernel_label("wgrad%dx%d_%dx64x32%s%s%s_split%d", KH, KW, p.bm, AV4 ? "_a4" : "", BV4 ? "_b4" : "",
+                     TF ? "_tf" : "", p.splits);
+    if (p.bm == 64)
+        launch_gemm<GatherLoader<64, 32, 1, 1, false, true, AV4, false>,
+                    GatherLoader<64, 32, KH, KW, false, true, BV4, TF>, 64, 64, 32, 2, 2>(da, db, dc, p.M, p.N, p.K,
+                                                                                          p.splits, st);
+    else
+        launch_gemm<GatherLoader<128, 32, 1, 1, false, true, AV4, false>,
+                    GatherLoader<64, 32, KH, KW, false, true, BV4, TF>, 128, 64, 32, 2, 2>(da, db, dc, p.M, p.N, p.K,
+                                                                                           p.splits, st);
+}
+
 template <int KH, int KW, bool AV4, bool BV4>
 static void wgrad_gemm(const WgradPlan& p, const GatherDesc& da, const GatherDesc& db, const OutDesc& dc,
                        hipStream_t st) {
-    set_kernel_label("wgrad%dx%d_%dx64x32%s%s_split%d", KH, KW, p.bm, AV4 ? "_a4" : "", BV4 ? "_b4" : "", p.splits);
-    if (p.bm == 64)
-        launch_gemm<GatherLoader<64, 32, 1, 1, false, true, AV4>, GatherLoader<64, 32, KH, KW, false, true, BV4>, 64,
-                    64, 32, 2, 2>(da, db, dc, p.M, p.N, p.K, p.splits, st);
-    else
-        launch_gemm<GatherLoader<128, 32, 1, 1, false, true, AV4>, GatherLoader<64, 32, KH, KW, false, true, BV4>,
-                    128, 64, 32, 2, 2>(da, db, dc, p.M, p.N, p.K, p.splits, st);
+    if constexpr (KH != 7) {
+        if (db.scale) {
+            wgrad_gemm_tf<KH, KW, AV4, BV4, true>(p, da, db, dc, st);
+            return;
+        }
+    }
+    wgrad_gemm_tf<KH, KW, AV4, BV4, false>(p, da, db, dc, st);
 }
 
 }  // namespace scat
@@ -66,6 +81,8 @@ extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int
     if (int e = check_geom("scat_conv2d_wgrad", B, Cin, H, W, Cout, KH, KW, stride, pad, &OH, &OW)) return e;
     SCAT_REQUIRE(dy && x && dw, SCAT_E_ARG, "scat_conv2d_wgrad: null pointer");
     SCAT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), SCAT_E_ARG, "scat_conv2d_wgrad: scale/shift pair");
+    SCAT_REQUIRE(!(in_scale && KH == 7), SCAT_E_SHAPE, "scat_conv2d_wgrad: fused input transform not built for 7x7");
+    if (!in_scale) in_relu = 0;
     WgradPlan p = wgrad_plan(B, Cin, Cout, KH * KW, OH, OW);
     int64_t need = p.splits > 1 ? (int64_t)p.splits * p.M * p.N * sizeof(float) : 0;
     SCAT_REQUIRE(ws_bytes >= need && (need == 0 || ws), SCAT_E_WORKSPACE,
@@ -78,7 +95,7 @@ extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int
                   FastDiv::make(OH * OW), FastDiv::make(OW), (int64_t)B * Cin * H * W};
     OutDesc dc{};
     dc.p = p.splits > 1 ? (float*)ws : dw;
-    dc.mode = 0; dc.si = p.N; dc.sj = 1; dc.sz = (int64_t)p.M * p.N; dc.I = p.M; dc.J = p.N;
+    dc.mode = 0; dc.si = p.N; dc.sj = 1; dc.sz = (int64_t)p.M * p.N; dc.I = p.M; dc.J = p.N; dc.n = (int64_t)p.M * p.N;
     hipStream_t st = (hipStream_t)stream;
     const bool av4 = (OH * OW) % 4 == 0 && ((uintptr_t)dy & 15) == 0;
     const bool bv4 = KH == 1 && stride == 1 && pad == 0 && (H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0;

@@ -21,6 +21,8 @@
 // Reference semantics replaced: torch.nn.Conv2d / nn.Linear as called from
 // models/resnet.py:62-98,103-162 and models/vision_transformer.py:28-79 (fp32).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace scat {
@@ -63,6 +65,7 @@ struct OutDesc {
     const float* bias;    // optional
     int bias_mode;        // 1: bias[i]  2: bias[j]
     int accumulate;       // C += result
+    int64_t n;            // floats addressable from p (+ z*sz in mode 0): buffer bounds
 };
 
 // ---------------------------------------------------------------- loaders
@@ -105,6 +108,8 @@ struct MatLoader {
         else       { i_t = tid % BI; k_t = tid / BI; }
         rs = make_rsrc(d.p + (int64_t)z * d.sz, d.n);
         i_t += i0;
+#pragma unroll
+        for (int r = 0; r < NE; ++r) v[r] = 0.f;
     }
     __device__ __forceinline__ void load(const MatDesc& d, int k0, int kend) {
 #pragma unroll
@@ -137,7 +142,8 @@ struct MatLoader {
 // of a stride-2 conv: only taps of matching parity contribute).  PIXK: the pixel index is the
 // contraction index (weight gradient).  V4: 16-B loads along 4 consecutive pixels — only for
 // KH=KW=1, stride 1, no padding, (PH*PW) % 4 == 0.
-template <int BI, int BK, int KH, int KW, bool D2, bool PIXK, bool V4 = false>
+// TF: the fused per-channel scale/shift(+ReLU) input transform is compiled in.
+template <int BI, int BK, int KH, int KW, bool D2, bool PIXK, bool V4 = false, bool TF = false>
 struct GatherLoader {
     static constexpr int KK = KH * KW;
     static constexpr int NE = BI * BK / NT;
@@ -199,6 +205,8 @@ struct GatherLoader {
     __device__ __forceinline__ void init(const GatherDesc& d, int i0, int /*z*/) {
         rs = make_rsrc(d.p, d.n);
         okbits = 0;
+#pragma unroll
+        for (int r = 0; r < NE; ++r) v[r] = 0.f;
         if (!PIXK) {
             decode_pix(d, i0 + pix_l());
         } else {
@@ -209,8 +217,8 @@ struct GatherLoader {
                 bool ok = ct < d.nct;
                 cttap[r] = ok ? tap : -1;
                 ctoff[r] = c * d.H * d.W + tap_off(d, tap);
-                csc[r] = (ok && d.scale) ? d.scale[c] : 1.f;
-                csh[r] = (ok && d.scale) ? d.shift[c] : 0.f;
+                csc[r] = (TF && ok) ? d.scale[c] : 1.f;
+                csh[r] = (TF && ok) ? d.shift[c] : 0.f;
             }
         }
     }
@@ -233,7 +241,7 @@ struct GatherLoader {
                     v[r] = bload(rs, off);
                 }
                 okbits |= (ok ? 1u : 0u) << r;
-                if (d.scale) {
+                if constexpr (TF) {
                     int cc = ct < kend ? c : 0;
                     rsc[r] = d.scale[cc];
                     rsh[r] = d.shift[cc];
@@ -265,9 +273,12 @@ struct GatherLoader {
 #pragma unroll
             for (int q = 0; q < PV; ++q) {
                 float x = v[PV * r + q];
-                if (d.scale) x = fmaf(x, PIXK ? csc[r] : rsc[r], PIXK ? csh[r] : rsh[r]);
-                if (d.relu) x = fmaxf(x, 0.f);
-                t[q] = ok ? x : 0.f;
+                if constexpr (TF) {
+                    x = fmaf(x, PIXK ? csc[r] : rsc[r], PIXK ? csh[r] : rsh[r]);
+                    x = d.relu ? fmaxf(x, 0.f) : x;
+                    x = ok ? x : 0.f;      // padding stays zero after the transform
+                }
+                t[q] = x;                  // without a transform the bounds-checked load already gave 0
             }
             const int pl = pix_l(), cl = ct_l(r);
             if (!PIXK) {          // tile[k = ct][i = pixel]: pixels contiguous
@@ -291,17 +302,27 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
 }
 
-template <class LA, class LB, int BM, int BN, int BK, int WM, int WN>
+// PF = k-pairs whose LDS fragments are fetched ahead as one register chunk (0: fetch per k-pair).
+// ABL (timing experiments only, results invalid): 1 no global loads, 2 +no LDS stores, 3 +no barrier, 4 +no ds_reads.
+template <class LA, class LB, int BM, int BN, int BK, int WM, int WN, int PF = 0, int SCHED = 0, int ABL = 0>
 __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename LB::Desc db, OutDesc dc,
-                                                  int M, int N, int K, int kchunk) {
+                                                  int M, int N, int K, int kchunk, int stagger) {
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     static_assert(WM * WN == 4 && MI >= 1 && NI >= 1, "wave layout");
     constexpr int SA = BM + LPAD, SB = BN + LPAD;
-    __shared__ float lds[2 * BK * (SA + SB)];
-    // layout: A buffers 0,1 then B buffers 0,1
+    extern __shared__ __align__(16) float lds[];   // 2*BK*(SA+SB) floats: A buffers 0,1 then B buffers 0,1
     auto As = [&](int buf) -> float* { return lds + buf * (BK * SA); };
     auto Bs = [&](int buf) -> float* { return lds + 2 * BK * SA + buf * (BK * SB); };
 
+    // De-phase the workgroups that share a CU: identical workgroups started together stay in lockstep
+    // (all compute, then all store), so the MFMA pipes idle while HBM drains the epilogues and vice versa.
+    // The first resident generation is delayed by slot*stagger cycles; later generations inherit the skew.
+    // Placement (which blocks share a CU) is only a speed assumption, never correctness.
+    if (stagger > 0 && blockIdx.x < 1024 && blockIdx.x >= 256) {
+        const long long t0 = wall_clock64();
+        const long long wait = (long long)(blockIdx.x >> 8) * stagger;   // 100 MHz ticks
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, mt * nt);
     const int i0 = (tile % mt) * BM, j0 = (tile / mt) * BN;   // m fastest: neighbours share the B panel
@@ -333,60 +354,146 @@ __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename
         lb.store(db, Bs(0));
     }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            la.load(da, kbeg + (kt + 1) * BK, kend);
-            lb.load(db, kbeg + (kt + 1) * BK, kend);
+    // one K-step on LDS buffer `cur`; NEXT: also stage the following tile (loads issued first so they are in
+    // flight under the MFMAs, written to the other LDS buffer afterwards).  No branches inside: the body is
+    // one scheduling region.
+    auto kstep = [&](int cur, int knext, auto next_tag) {
+        constexpr bool NEXT = decltype(next_tag)::value;
+        if constexpr (NEXT && ABL < 1) {
+            la.load(da, knext, kend);
+            lb.load(db, knext, kend);
         }
-        const float* as = As(cur) + wm * (BM / WM) + l31;
-        const float* bs = Bs(cur) + wn * (BN / WN) + l31;
+        const float* as = As(cur) + wm * (BM / WM) + l31 + lh * SA;
+        const float* bs = Bs(cur) + wn * (BN / WN) + l31 + lh * SB;
+        if constexpr (PF == 0) {
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float av[MI], bv[NI];
+            for (int kk = 0; kk < BK; kk += 2) {
+                float av[MI], bv[NI];
 #pragma unroll
-            for (int a = 0; a < MI; ++a) av[a] = as[(kk + lh) * SA + a * 32];
+                for (int a = 0; a < MI; ++a) av[a] = ABL >= 4 ? (float)(lane + a) : as[kk * SA + a * 32];
 #pragma unroll
-            for (int b = 0; b < NI; ++b) bv[b] = bs[(kk + lh) * SB + b * 32];
+                for (int b = 0; b < NI; ++b) bv[b] = ABL >= 4 ? (float)(lane - b) : bs[kk * SB + b * 32];
 #pragma unroll
-            for (int a = 0; a < MI; ++a)
+                for (int a = 0; a < MI; ++a)
 #pragma unroll
-                for (int b = 0; b < NI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < NI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+        } else {
+            // register double-buffered fragments: the ds_reads of chunk c+1 are in flight while the MFMAs
+            // of chunk c issue
+            constexpr int NC = BK / 2 / PF;
+            float av[2][PF][MI], bv[2][PF][NI];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+#pragma unroll
+                for (int a = 0; a < MI; ++a) av[0][q][a] = as[(2 * q) * SA + a * 32];
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bv[0][q][b] = bs[(2 * q) * SB + b * 32];
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (c + 1 < NC) {
+#pragma unroll
+                    for (int q = 0; q < PF; ++q) {
+#pragma unroll
+                        for (int a = 0; a < MI; ++a)
+                            av[(c + 1) & 1][q][a] = as[(2 * ((c + 1) * PF + q)) * SA + a * 32];
+#pragma unroll
+                        for (int b = 0; b < NI; ++b)
+                            bv[(c + 1) & 1][q][b] = bs[(2 * ((c + 1) * PF + q)) * SB + b * 32];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < PF; ++q)
+#pragma unroll
+                    for (int a = 0; a < MI; ++a)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][q][a], bv[c & 1][q][b],
+                                                                             acc[a][b], 0, 0, 0);
+            }
         }
-        if (kt + 1 < nk) {
+        if constexpr (NEXT && ABL < 2) {
             la.store(da, As(cur ^ 1));
             lb.store(db, Bs(cur ^ 1));
         }
-        __syncthreads();
-    }
+        if constexpr (SCHED == 1) __builtin_amdgcn_iglp_opt(0);
+        if constexpr (SCHED == 2) __builtin_amdgcn_iglp_opt(1);
+        if constexpr (ABL < 3) __syncthreads();
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt & 1, kbeg + (kt + 1) * BK, std::true_type{});
+    if (nk > 0) kstep((nk - 1) & 1, 0, std::false_type{});
 
-    // epilogue: C/D map of the 32x32 MFMA — col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // Branch-free: 32-bit element offsets, raw buffer stores whose out-of-range lanes (tile edge) are
+    // dropped by the hardware bounds check; the (accumulate, bias) variants are separate straight-line
+    // copies selected once by uniform branches.
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(dc.p + (dc.mode == 1 ? 0 : (int64_t)z * dc.sz), dc.n);
+    const int rstride = dc.mode == 1 ? dc.HW : (int)dc.si;
+    int coloff[NI];
+    bool colok[NI];
+    float bj[NI];
 #pragma unroll
     for (int b = 0; b < NI; ++b) {
         const int j = j0 + wn * (BN / WN) + b * 32 + l31;
-        if (j >= N) continue;
-        int64_t joff;
+        colok[b] = j < N;
+        const int jc = colok[b] ? j : 0;
         if (dc.mode == 1) {
-            uint32_t n = dc.dHW.div((uint32_t)j);
-            joff = (int64_t)n * dc.C * dc.HW + (j - n * dc.HW);
+            uint32_t n = dc.dHW.div((uint32_t)jc);
+            coloff[b] = (int)n * dc.C * dc.HW + (jc - (int)n * dc.HW);
         } else {
-            joff = (int64_t)z * dc.sz + (int64_t)j * dc.sj;
+            coloff[b] = jc * (int)dc.sj;
         }
-        const float bj = (dc.bias && dc.bias_mode == 2) ? dc.bias[j] : 0.f;
+        bj[b] = (dc.bias && dc.bias_mode == 2) ? dc.bias[jc] : 0.f;
+    }
+    const int ibase = i0 + wm * (BM / WM) + 4 * lh;
+    auto emit = [&](auto acc_tag, auto bias_tag) {
+        constexpr bool ACC = decltype(acc_tag)::value;
+        constexpr bool BIASI = decltype(bias_tag)::value;
 #pragma unroll
         for (int a = 0; a < MI; ++a) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = i0 + wm * (BM / WM) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (i >= M) continue;
-                float val = acc[a][b][r] + bj;
-                if (dc.bias && dc.bias_mode == 1) val += dc.bias[i];
-                float* dst = dc.p + joff + (dc.mode == 1 ? (int64_t)i * dc.HW : (int64_t)i * dc.si);
-                if (dc.accumulate) val += *dst;
-                *dst = val;
+            for (int rq = 0; rq < 4; ++rq) {          // 4 registers = 4 consecutive rows
+                int voff[4][NI];
+                float val[4][NI];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int i = ibase + a * 32 + rr + 8 * rq;
+                    const bool rowok = i < M;
+                    const float bi = BIASI ? dc.bias[rowok ? i : 0] : 0.f;
+#pragma unroll
+                    for (int b = 0; b < NI; ++b) {
+                        voff[rr][b] = (rowok && colok[b]) ? (coloff[b] + i * rstride) * 4 : OOB;
+                        val[rr][b] = acc[a][b][rq * 4 + rr] + bj[b] + bi;
+                    }
+                }
+                if constexpr (ACC) {
+                    float old[4][NI];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b) old[rr][b] = bload(rc, voff[rr][b]);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b) val[rr][b] += old[rr][b];
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int b = 0; b < NI; ++b)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[rr][b]), rc, voff[rr][b], 0, 0);
             }
         }
+    };
+    const bool biasi = dc.bias && dc.bias_mode == 1;
+    if (dc.accumulate) {
+        if (biasi) emit(std::true_type{}, std::true_type{});
+        else emit(std::true_type{}, std::false_type{});
+    } else {
+        if (biasi) emit(std::false_type{}, std::true_type{});
+        else emit(std::false_type{}, std::false_type{});
     }
 }
 
@@ -394,13 +501,22 @@ __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int splits,
                                      int accumulate);
 
-template <class LA, class LB, int BM, int BN, int BK, int WM, int WN>
+template <class LA, class LB, int BM, int BN, int BK, int WM, int WN, int PF = 0, int SCHED = 0, int ABL = 0>
 static inline void launch_gemm(const typename LA::Desc& da, const typename LB::Desc& db, const OutDesc& dc, int M,
-                               int N, int K, int splits, hipStream_t st) {
+                               int N, int K, int splits, hipStream_t st, int stagger = 0) {
     int mt = cdiv(M, BM), nt = cdiv(N, BN);
     int kchunk = cdiv(cdiv(K, splits), BK) * BK;
     dim3 grid(mt * nt, 1, splits);
-    hipLaunchKernelGGL((gemm_kernel<LA, LB, BM, BN, BK, WM, WN>), grid, dim3(NT), 0, st, da, db, dc, M, N, K, kchunk);
+    constexpr size_t lds_bytes = sizeof(float) * 2 * BK * (BM + BN + 2 * LPAD);
+    auto kern = gemm_kernel<LA, LB, BM, BN, BK, WM, WN, PF, SCHED, ABL>;
+    if constexpr (lds_bytes > 64 * 1024) {
+        static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)lds_bytes) == hipSuccess);
+        (void)once;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds_bytes, st, da, db, dc, M, N, K, kchunk, stagger);
 }
+
+int tuning();   // SCAT_TUNE environment knob for kernel-variant experiments (0 = shipped default)
 
 }  // namespace scat

@@ -75,15 +75,18 @@ extern "C" int scat_gemm(const float* a, int64_t a_si, int64_t a_sk, const float
     SCAT_REQUIRE(fits_i32(((int64_t)(M - 1) * a_si + (int64_t)(K - 1) * a_sk + 1) * 4) &&
                      fits_i32(((int64_t)(N - 1) * b_sj + (int64_t)(K - 1) * b_sk + 1) * 4),
                  SCAT_E_SHAPE, "scat_gemm: operand exceeds 2 GiB");
+    SCAT_REQUIRE(fits_i32(((int64_t)(M - 1) * c_si + (int64_t)(N - 1) * c_sj + 1) * 4), SCAT_E_SHAPE,
+                 "scat_gemm: output exceeds 2 GiB");
     MatDesc da{a, a_si, a_sk, 0, M, K, (int64_t)(M - 1) * a_si + (int64_t)(K - 1) * a_sk + 1};
     MatDesc db{b, b_sj, b_sk, 0, N, K, (int64_t)(N - 1) * b_sj + (int64_t)(K - 1) * b_sk + 1};
     OutDesc dc{};
     hipStream_t st = (hipStream_t)stream;
     if (p.splits > 1) {
-        dc.p = (float*)ws; dc.mode = 0; dc.si = N; dc.sj = 1; dc.sz = (int64_t)M * N; dc.I = M; dc.J = N;
+        dc.p = (float*)ws; dc.mode = 0; dc.si = N; dc.sj = 1; dc.sz = (int64_t)M * N; dc.I = M; dc.J = N; dc.n = (int64_t)M * N;
     } else {
         dc.p = c; dc.mode = 0; dc.si = c_si; dc.sj = c_sj; dc.sz = 0; dc.I = M; dc.J = N;
         dc.bias = bias; dc.bias_mode = bias_mode; dc.accumulate = accumulate;
+        dc.n = (int64_t)(M - 1) * c_si + (int64_t)(N - 1) * c_sj + 1;
     }
     const bool ak = (a_sk == 1), bk = (b_sk == 1);
     // 16-B loads along k where the contraction dim is contiguous, a multiple of 4, and rows stay 16-B aligned

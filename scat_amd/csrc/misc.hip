@@ -2,6 +2,7 @@
 // All HBM-bound (or tiny): grid-stride, 16-B accesses where alignment allows.
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -24,6 +25,11 @@ void set_kernel_label(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_label, sizeof(g_label), fmt, ap);
     va_end(ap);
+}
+
+int tuning() {
+    static int v = [] { const char* e = getenv("SCAT_TUNE"); return e ? atoi(e) : 0; }();
+    return v;
 }
 
 static inline int grid_for(int64_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
