@@ -42,6 +42,12 @@ int scat_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
 /* dx[B,Cin,H,W] (+)= conv_transpose(dy[B,Cout,OH,OW], w).  wt = scat_conv2d_wt() output. */
 int scat_conv2d_dgrad(const float* dy, const float* wt, float* dx, int B, int Cin, int H, int W, int Cout, int KH,
                       int KW, int stride, int pad, int accumulate, void* stream);
+/* Stride-2 data-gradient decomposed by input-pixel parity (1x1/pad 0 and 3x3/pad 1): four stride-1
+ * contractions over only the taps that can contribute (1+2+2+4 of 9), i.e. no MFMA work on structural
+ * zeros.  Takes the ORIGINAL weights w[Cout,Cin,KH,KW]; ws: scat_conv2d_dgrad_s2_ws() bytes. */
+int64_t scat_conv2d_dgrad_s2_ws(int Cin, int Cout, int KH, int KW);
+int scat_conv2d_dgrad_s2(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W, int Cout, int KH,
+                         int KW, int pad, int accumulate, void* ws, int64_t ws_bytes, void* stream);
 /* wt[Cin][Cout*KH*KW] = w[Cout][Cin][KH][KW] re-laid for the data-gradient contraction. */
 int scat_conv2d_wt(const float* w, float* wt, int Cout, int Cin, int KH, int KW, void* stream);
 /* dw[Cout,Cin,KH,KW] = sum over pixels dy * relu(x*scale+shift).  Deterministic two-stage

@@ -80,6 +80,39 @@ static void conv_gemm(const MatDesc& da, const GatherDesc& db, const OutDesc& dc
     conv_gemm_tf<KH, KW, D2, false>(da, db, dc, M, N, K, bv4, st);
 }
 
+// stride-2 data-gradient, decomposed by input-pixel parity: class (py,px) is a stride-1 gather over dy with the
+// KHc x KWc taps of matching parity (1..4 of the 9), so no MFMA work is spent on structurally-zero taps.
+__global__ void wt_class_kernel(const float* __restrict__ w, float* __restrict__ wtc, int Cout, int Cin, int KH,
+                                int KW, int kh0, int kw0, int KHc, int KWc) {
+    // wtc[ci][(co*KHc + kky)*KWc + kkx] = w[co][ci][kh0 + 2*kky][kw0 + 2*kkx]
+    const int KKc = KHc * KWc;
+    int64_t n = (int64_t)Cin * Cout * KKc;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        int t = e % KKc;
+        int64_t r = e / KKc;
+        int co = r % Cout, ci = r / Cout;
+        int kky = t / KWc, kkx = t % KWc;
+        wtc[e] = w[(((int64_t)co * Cin + ci) * KH + kh0 + 2 * kky) * KW + kw0 + 2 * kkx];
+    }
+}
+
+template <int KHc, int KWc>
+static void dgrad_class_gemm(const MatDesc& da, const GatherDesc& db, const OutDesc& dc, int M, int N, int K, bool bv4,
+                             hipStream_t st) {
+    const Cfg cfg = pick_cfg(M, N);
+    static const char* const names[] = {"128x128", "128x64", "64x128", "64x64"};
+    set_kernel_label("dgrad_s2_class%dx%d_%sx16%s", KHc, KWc, names[cfg], bv4 ? "_b4" : "");
+    if constexpr (KHc == 1 && KWc == 1) {
+        if (bv4) {
+            conv_gemm_cfg<1, 1, false, 4, true, false>(cfg, da, db, dc, M, N, K, st);
+            set_kernel_label("dgrad_s2_class1x1_%sx16_b4", names[cfg]);
+            return;
+        }
+    }
+    conv_gemm_cfg<KHc, KWc, false, 4, false, false>(cfg, da, db, dc, M, N, K, st);
+    set_kernel_label("dgrad_s2_class%dx%d_%sx16", KHc, KWc, names[cfg]);
+}
+
 __global__ void wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int KK) {
     // wt[ci][co*KK + t] = w[co][ci][t]
     int64_t n = (int64_t)Cout * Cin * KK;
@@ -106,7 +139,7 @@ extern "C" int scat_conv2d_fwd(const float* x, const float* w, const float* bias
     if (!in_scale) in_relu = 0;
     const int KK = KH * KW, K = Cin * KK, N = B * OH * OW;
     MatDesc da{w, K, 1, 0, Cout, K, (int64_t)Cout * K};
-    GatherDesc db{x, in_scale, in_shift, in_relu, Cin, H, W, OH, OW, stride, 1, -pad, N, K,
+    GatherDesc db{x, in_scale, in_shift, in_relu, Cin, H, W, OH, OW, stride, 1, -pad, -pad, N, K,
                   FastDiv::make(OH * OW), FastDiv::make(OW), (int64_t)B * Cin * H * W};
     OutDesc dc{};
     dc.p = y; dc.mode = 1; dc.I = Cout; dc.J = N; dc.C = Cout; dc.HW = OH * OW; dc.dHW = FastDiv::make(OH * OW);
@@ -138,7 +171,7 @@ extern "C" int scat_conv2d_dgrad(const float* dy, const float* wt, float* dx, in
     const int KK = KH * KW, K = Cout * KK, N = B * H * W;
     MatDesc da{wt, K, 1, 0, Cin, K, (int64_t)Cin * K};
     // source = dy[B,Cout,OH,OW]; pixel grid = input pixels; t = y*1 + kh*(-1) + pad, divisor = stride
-    GatherDesc db{dy, nullptr, nullptr, 0, Cout, OH, OW, H, W, 1, -1, pad, N, K, FastDiv::make(H * W),
+    GatherDesc db{dy, nullptr, nullptr, 0, Cout, OH, OW, H, W, 1, -1, pad, pad, N, K, FastDiv::make(H * W),
                   FastDiv::make(W), (int64_t)B * Cout * OH * OW};
     OutDesc dc{};
     dc.p = dx; dc.mode = 1; dc.I = Cin; dc.J = N; dc.C = Cin; dc.HW = H * W; dc.dHW = FastDiv::make(H * W);
@@ -153,5 +186,59 @@ extern "C" int scat_conv2d_dgrad(const float* dy, const float* wt, float* dx, in
         else conv_gemm<3, 3, true>(da, db, dc, Cin, N, K, false, st);
     }
     SCAT_LAUNCH_CHECK("scat_conv2d_dgrad");
+    return SCAT_OK;
+}
+
+extern "C" int64_t scat_conv2d_dgrad_s2_ws(int Cin, int Cout, int KH, int KW) {
+    return (int64_t)Cin * Cout * KH * KW * sizeof(float);
+}
+
+extern "C" int scat_conv2d_dgrad_s2(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W,
+                                    int Cout, int KH, int KW, int pad, int accumulate, void* ws, int64_t ws_bytes,
+                                    void* stream) {
+    int OH, OW;
+    if (int e = check_geom("scat_conv2d_dgrad_s2", B, Cin, H, W, Cout, KH, KW, 2, pad, &OH, &OW)) return e;
+    SCAT_REQUIRE(dy && w && dx, SCAT_E_ARG, "scat_conv2d_dgrad_s2: null pointer");
+    SCAT_REQUIRE((KH == 1 && pad == 0) || (KH == 3 && pad == 1), SCAT_E_SHAPE,
+                 "scat_conv2d_dgrad_s2: only 1x1/pad0 and 3x3/pad1 (use scat_conv2d_dgrad otherwise)");
+    SCAT_REQUIRE((Cout * KH * KW) % 4 == 0 && Cout % 4 == 0, SCAT_E_SHAPE, "scat_conv2d_dgrad_s2: Cout % 4 != 0");
+    SCAT_REQUIRE(ws && ws_bytes >= scat_conv2d_dgrad_s2_ws(Cin, Cout, KH, KW), SCAT_E_WORKSPACE,
+                 "scat_conv2d_dgrad_s2: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate && KH == 1) {   // 1x1: only even pixels receive gradient, the rest of dx is zero
+        if (hipMemsetAsync(dx, 0, (size_t)B * Cin * H * W * sizeof(float), st) != hipSuccess) {
+            set_error("scat_conv2d_dgrad_s2: memset failed");
+            return SCAT_E_LAUNCH;
+        }
+    }
+    float* wtc = (float*)ws;
+    for (int py = 0; py < 2; ++py) {
+        for (int px = 0; px < 2; ++px) {
+            const int kh0 = (py + pad) & 1, kw0 = (px + pad) & 1;
+            const int KHc = (KH - kh0 + 1) / 2, KWc = (KW - kw0 + 1) / 2;   // taps of matching parity
+            const int QH = (H - py + 1) / 2, QW = (W - px + 1) / 2;         // input pixels in this class
+            if (KHc <= 0 || KWc <= 0 || QH <= 0 || QW <= 0) continue;       // 1x1: only class (0,0) has a tap
+            const int KKc = KHc * KWc, K = Cout * KKc, N = B * QH * QW;
+            int64_t nw = (int64_t)Cin * K;
+            int blocks = (int)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048);
+            hipLaunchKernelGGL(wt_class_kernel, dim3(blocks), dim3(256), 0, st, w, wtc, Cout, Cin, KH, KW, kh0, kw0,
+                               KHc, KWc);
+            MatDesc da{wtc, K, 1, 0, Cin, K, nw};
+            // oy = q + floor((py+pad)/2) - kky  over the class grid [QH][QW]
+            GatherDesc db{dy, nullptr, nullptr, 0, Cout, OH, OW, QH, QW, 1, -1, (py + pad) >> 1, (px + pad) >> 1, N, K,
+                          FastDiv::make(QH * QW), FastDiv::make(QW), (int64_t)B * Cout * OH * OW};
+            OutDesc dc{};
+            dc.p = dx; dc.mode = 2; dc.I = Cin; dc.J = N; dc.C = Cin; dc.HW = H * W; dc.W = W; dc.QW = QW;
+            dc.sub_s = 2; dc.sub_y = py; dc.sub_x = px; dc.dQHW = FastDiv::make(QH * QW); dc.dQW = FastDiv::make(QW);
+            dc.accumulate = accumulate; dc.n = (int64_t)B * Cin * H * W;
+            const bool bv4 = KKc == 1 && QH == OH && QW == OW && (OH * OW) % 4 == 0 && ((uintptr_t)dy & 15) == 0 &&
+                             ((py + pad) >> 1) == 0 && ((px + pad) >> 1) == 0;
+            if (KHc == 1 && KWc == 1) dgrad_class_gemm<1, 1>(da, db, dc, Cin, N, K, bv4, st);
+            else if (KHc == 1) dgrad_class_gemm<1, 2>(da, db, dc, Cin, N, K, false, st);
+            else if (KWc == 1) dgrad_class_gemm<2, 1>(da, db, dc, Cin, N, K, false, st);
+            else dgrad_class_gemm<2, 2>(da, db, dc, Cin, N, K, false, st);
+        }
+    }
+    SCAT_LAUNCH_CHECK("scat_conv2d_dgrad_s2");
     return SCAT_OK;
 }

@@ -89,9 +89,9 @@ extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int
                  "scat_conv2d_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
     const int npix = B * OH * OW;
     // A: dy as [Cout][pixel]; B: x through the forward conv arithmetic as [pixel][(ci,kh,kw)]
-    GatherDesc da{dy, nullptr, nullptr, 0, Cout, OH, OW, OH, OW, 1, 0, 0, npix, Cout, FastDiv::make(OH * OW),
+    GatherDesc da{dy, nullptr, nullptr, 0, Cout, OH, OW, OH, OW, 1, 0, 0, 0, npix, Cout, FastDiv::make(OH * OW),
                   FastDiv::make(OW), (int64_t)B * Cout * OH * OW};
-    GatherDesc db{x, in_scale, in_shift, in_relu, Cin, H, W, OH, OW, stride, 1, -pad, npix, Cin * KH * KW,
+    GatherDesc db{x, in_scale, in_shift, in_relu, Cin, H, W, OH, OW, stride, 1, -pad, -pad, npix, Cin * KH * KW,
                   FastDiv::make(OH * OW), FastDiv::make(OW), (int64_t)B * Cin * H * W};
     OutDesc dc{};
     dc.p = p.splits > 1 ? (float*)ws : dw;

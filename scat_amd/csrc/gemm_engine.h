@@ -48,7 +48,8 @@ struct GatherDesc {       // elem(pix, ct) of an NCHW tensor through conv arithm
     int relu;
     int C, H, W;          // source tensor: [Nimg][C][H][W]
     int PH, PW;           // pixel grid the GEMM index runs over
-    int a, b, c0;         // source row  t = y*a + kh*b + c0  (columns alike)
+    int a, b, c0;         // source row  t = y*a + kh*b + c0
+    int c0x;              // source col  t = x*a + kw*b + c0x
     int npix;             // Nimg*PH*PW
     int nct;              // C*KH*KW
     FastDiv dPHW, dPW;
@@ -58,6 +59,9 @@ struct GatherDesc {       // elem(pix, ct) of an NCHW tensor through conv arithm
 struct OutDesc {
     float* p;
     int mode;             // 0: C[z*sz + i*si + j*sj]   1: NCHW, j = pixel: [(j/HW)][i][j%HW]
+                          // 2: NCHW, j = pixel of a strided sub-grid [QH][QW] -> (qy*sub_s + sub_y, qx*sub_s + sub_x)
+    int W, QW, sub_s, sub_y, sub_x;
+    FastDiv dQHW, dQW;
     int64_t si, sj, sz;
     int I, J;
     int C, HW;
@@ -176,7 +180,7 @@ struct GatherLoader {
         uint32_t r = pix - n * (d.PH * d.PW);
         uint32_t y = d.dPW.div(r);
         uint32_t x = r - y * d.PW;
-        int ty0 = (int)y * d.a + d.c0, tx0 = (int)x * d.a + d.c0;
+        int ty0 = (int)y * d.a + d.c0, tx0 = (int)x * d.a + d.c0x;
         uint32_t rowm = 0, colm = 0;
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
@@ -429,8 +433,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename
     // Branch-free: 32-bit element offsets, raw buffer stores whose out-of-range lanes (tile edge) are
     // dropped by the hardware bounds check; the (accumulate, bias) variants are separate straight-line
     // copies selected once by uniform branches.
-    const __amdgpu_buffer_rsrc_t rc = make_rsrc(dc.p + (dc.mode == 1 ? 0 : (int64_t)z * dc.sz), dc.n);
-    const int rstride = dc.mode == 1 ? dc.HW : (int)dc.si;
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(dc.p + (dc.mode != 0 ? 0 : (int64_t)z * dc.sz), dc.n);
+    const int rstride = dc.mode != 0 ? dc.HW : (int)dc.si;
     int coloff[NI];
     bool colok[NI];
     float bj[NI];
@@ -442,6 +446,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename
         if (dc.mode == 1) {
             uint32_t n = dc.dHW.div((uint32_t)jc);
             coloff[b] = (int)n * dc.C * dc.HW + (jc - (int)n * dc.HW);
+        } else if (dc.mode == 2) {
+            uint32_t n = dc.dQHW.div((uint32_t)jc);
+            uint32_t r = jc - n * dc.dQHW.d;
+            uint32_t qy = dc.dQW.div(r), qx = r - qy * dc.QW;
+            coloff[b] = (int)n * dc.C * dc.HW + ((int)qy * dc.sub_s + dc.sub_y) * dc.W + (int)qx * dc.sub_s + dc.sub_x;
         } else {
             coloff[b] = jc * (int)dc.sj;
         }

@@ -31,6 +31,8 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
     }
 }
 
+static inline int ew_grid(int64_t n) { return (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384); }
+
 static int bn_splits(int B, int C) {
     int s = cdiv(2048, C);
     if (s > B) s = B;
@@ -39,25 +41,25 @@ static int bn_splits(int B, int C) {
 
 // ---------------------------------------------------------------- BN forward statistics
 
+// Each block reduces channel c over images n = s, s+S, ...; the (image, pixel) pair is flattened so small
+// feature maps (7x7) still use every lane.  V = 4: 16-B loads (HW % 4 == 0).
+template <int V>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int B, int C, int HW, int S,
-                                                       double* __restrict__ part) {
+                                                       FastDiv dHWv, double* __restrict__ part) {
     const int c = blockIdx.x, s = blockIdx.y;
+    const int nimg = (B - s + S - 1) / S, hwv = HW / V;
     double s1 = 0, s2 = 0;
-    for (int n = s; n < B; n += S) {
-        const float* p = x + ((int64_t)n * C + c) * HW;
-        if ((HW & 3) == 0) {
-            const float4* p4 = (const float4*)p;
-            for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
-                float4 v = p4[i];
-                s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-                s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
-            }
+    for (int idx = threadIdx.x; idx < nimg * hwv; idx += 256) {
+        const int nl = (int)dHWv.div((uint32_t)idx), i = idx - nl * hwv;
+        const float* p = x + ((int64_t)(s + nl * S) * C + c) * HW + i * V;
+        if (V == 4) {
+            float4 v = *(const float4*)p;
+            s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
         } else {
-            for (int i = threadIdx.x; i < HW; i += 256) {
-                double v = p[i];
-                s1 += v;
-                s2 += v * v;
-            }
+            double v = *p;
+            s1 += v;
+            s2 += v * v;
         }
     }
     __shared__ double sh[8];
@@ -108,34 +110,27 @@ __global__ void bn_eval_fold_kernel(const float* gamma, const float* beta, const
 
 // ---------------------------------------------------------------- BN apply
 
-template <bool VEC>
+// flat element-wise pass; channel of element e = (e / HW) % C by mul-shift division
+template <int V>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const float* __restrict__ res, int relu,
-                                                       float* __restrict__ y, int64_t rows, int C, int HW) {
-    // one (n,c) row per blockIdx.x step: the channel is block-uniform
-    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int c = (int)(row % C);
+                                                       float* __restrict__ y, int64_t nvec, FastDiv dHWv, FastDiv dC) {
+    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < nvec; e += gridDim.x * 256ll) {
+        const uint32_t row = dHWv.div((uint32_t)e);
+        const int c = (int)(row - dC.div(row) * dC.d);
         const float sc = scale[c], sh = shift[c];
-        const int64_t off = row * HW;
-        if (VEC) {
-            const float4* x4 = (const float4*)(x + off);
-            const float4* r4 = res ? (const float4*)(res + off) : nullptr;
-            float4* y4 = (float4*)(y + off);
-            for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
-                float4 v = x4[i];
-                v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
-                if (r4) { float4 r = r4[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                y4[i] = v;
-            }
+        if (V == 4) {
+            float4 v = ((const float4*)x)[e];
+            v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+            if (res) { float4 r = ((const float4*)res)[e]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            ((float4*)y)[e] = v;
         } else {
-            for (int i = threadIdx.x; i < HW; i += 256) {
-                float v = fmaf(x[off + i], sc, sh);
-                if (res) v += res[off + i];
-                if (relu) v = fmaxf(v, 0.f);
-                y[off + i] = v;
-            }
+            float v = fmaf(x[e], sc, sh);
+            if (res) v += res[e];
+            if (relu) v = fmaxf(v, 0.f);
+            y[e] = v;
         }
     }
 }
@@ -148,23 +143,36 @@ __device__ __forceinline__ float bn_mask(float dy, float x, float yv, bool has_y
     return dy;
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ yout, int relu,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, int B, int C, int HW,
-                                                            int S, double* __restrict__ part) {
+                                                            int S, FastDiv dHWv, double* __restrict__ part) {
     const int c = blockIdx.x, s = blockIdx.y;
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const int nimg = (B - s + S - 1) / S, hwv = HW / V;
+    const bool has_y = yout != nullptr;
     double s1 = 0, s2 = 0;
-    for (int n = s; n < B; n += S) {
-        const int64_t off = ((int64_t)n * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            float xv = x[off + i];
-            float g = bn_mask(dy[off + i], xv, yout ? yout[off + i] : 0.f, yout != nullptr, relu, sc, sh);
+    for (int idx = threadIdx.x; idx < nimg * hwv; idx += 256) {
+        const int nl = (int)dHWv.div((uint32_t)idx), i = idx - nl * hwv;
+        const int64_t off = ((int64_t)(s + nl * S) * C + c) * HW + i * V;
+        float xv[V], gv[V], yv[V];
+        if (V == 4) {
+            float4 t = *(const float4*)(x + off); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            t = *(const float4*)(dy + off); gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+            if (has_y) { t = *(const float4*)(yout + off); yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w; }
+        } else {
+            xv[0] = x[off]; gv[0] = dy[off];
+            if (has_y) yv[0] = yout[off];
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            float g = bn_mask(gv[q], xv[q], has_y ? yv[q] : 0.f, has_y, relu, sc, sh);
             s1 += g;
-            s2 += (double)g * ((xv - mu) * is);
+            s2 += (double)g * ((xv[q] - mu) * is);
         }
     }
     __shared__ double shm[8];
@@ -192,6 +200,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, i
 }
 
 // dx may alias dy, dres may alias dy: every element is read before it is written by the same thread
+template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, const float* __restrict__ x,
                                                            const float* __restrict__ yout, int relu,
                                                            const float* __restrict__ scale,
@@ -200,20 +209,38 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ coef, float* dx,
-                                                           float* dres, int dres_acc, int64_t rows,
-                                                           int C, int HW) {
-    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int c = (int)(row % C);
+                                                           float* dres, int dres_acc, int64_t nvec, FastDiv dHWv,
+                                                           FastDiv dC) {
+    const bool has_y = yout != nullptr;
+    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < nvec; e += gridDim.x * 256ll) {
+        const uint32_t row = dHWv.div((uint32_t)e);
+        const int c = (int)(row - dC.div(row) * dC.d);
         const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
         const float k1 = coef[2 * c], k2 = coef[2 * c + 1], gi = gamma[c] * is;
-        const int64_t off = row * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            float xv = x[off + i];
-            float g = bn_mask(dy[off + i], xv, yout ? yout[off + i] : 0.f, yout != nullptr, relu, sc, sh);
-            float xh = (xv - mu) * is;
-            float r = (dres && dres_acc) ? dres[off + i] : 0.f;
-            dx[off + i] = gi * (g - k1 - xh * k2);
-            if (dres) dres[off + i] = r + g;
+        float xv[V], gv[V], yv[V], rv[V], ov[V];
+        if (V == 4) {
+            float4 t = ((const float4*)x)[e]; xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            t = ((const float4*)dy)[e]; gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+            if (has_y) { t = ((const float4*)yout)[e]; yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w; }
+            if (dres && dres_acc) { t = ((const float4*)dres)[e]; rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
+        } else {
+            xv[0] = x[e]; gv[0] = dy[e];
+            if (has_y) yv[0] = yout[e];
+            if (dres && dres_acc) rv[0] = dres[e];
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            float g = bn_mask(gv[q], xv[q], has_y ? yv[q] : 0.f, has_y, relu, sc, sh);
+            float xh = (xv[q] - mu) * is;
+            ov[q] = gi * (g - k1 - xh * k2);
+            rv[q] = ((dres && dres_acc) ? rv[q] : 0.f) + g;
+        }
+        if (V == 4) {
+            ((float4*)dx)[e] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            if (dres) ((float4*)dres)[e] = make_float4(rv[0], rv[1], rv[2], rv[3]);
+        } else {
+            dx[e] = ov[0];
+            if (dres) dres[e] = rv[0];
         }
     }
 }
@@ -303,7 +330,12 @@ extern "C" int scat_bn_train_stats(const float* x, int B, int C, int HW, const f
     SCAT_REQUIRE(ws && ws_bytes >= scat_bn_ws(B, C, HW), SCAT_E_WORKSPACE, "scat_bn_train_stats: workspace too small");
     const int S = bn_splits(B, C);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(256), 0, st, x, B, C, HW, S, (double*)ws);
+    if ((HW & 3) == 0 && ((uintptr_t)x & 15) == 0)
+        hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(C, S), dim3(256), 0, st, x, B, C, HW, S, FastDiv::make(HW / 4),
+                           (double*)ws);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(C, S), dim3(256), 0, st, x, B, C, HW, S, FastDiv::make(HW),
+                           (double*)ws);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, C, S,
                        (double)B * HW, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
                        scale, shift);
@@ -326,15 +358,18 @@ extern "C" int scat_bn_apply(const float* x, const float* scale, const float* sh
                              float* y, int B, int C, int HW, void* stream) {
     SCAT_REQUIRE(x && scale && shift && y, SCAT_E_ARG, "scat_bn_apply: null pointer");
     SCAT_REQUIRE(B > 0 && C > 0 && HW > 0, SCAT_E_SHAPE, "scat_bn_apply: non-positive dimension");
-    const int64_t rows = (int64_t)B * C;
-    const int blocks = (int)(rows < 8192 ? rows : 8192);
+    const int64_t total = (int64_t)B * C * HW;
+    SCAT_REQUIRE(fits_i32(total), SCAT_E_SHAPE, "scat_bn_apply: tensor exceeds 2^31 elements");
     hipStream_t st = (hipStream_t)stream;
-    if ((HW & 3) == 0)
-        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(blocks), dim3(256), 0, st, x, scale, shift, residual, relu, y,
-                           rows, C, HW);
-    else
-        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(blocks), dim3(256), 0, st, x, scale, shift, residual, relu, y,
-                           rows, C, HW);
+    const bool vec = (HW & 3) == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
+    if (vec) {
+        const int64_t nv = total / 4;
+        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_grid(nv)), dim3(256), 0, st, x, scale, shift, residual, relu, y,
+                           nv, FastDiv::make(HW / 4), FastDiv::make(C));
+    } else {
+        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, x, scale, shift, residual, relu,
+                           y, total, FastDiv::make(HW), FastDiv::make(C));
+    }
     SCAT_LAUNCH_CHECK("scat_bn_apply");
     return SCAT_OK;
 }
@@ -351,14 +386,28 @@ extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, 
     double* part = (double*)ws;
     float* coef = (float*)(part + (int64_t)C * S * 2);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y_out, relu, scale, shift,
-                       save_mean, save_invstd, B, C, HW, S, part);
+    const int64_t total = (int64_t)B * C * HW;
+    SCAT_REQUIRE(fits_i32(total), SCAT_E_SHAPE, "scat_bn_bwd: tensor exceeds 2^31 elements");
+    const bool vec = (HW & 3) == 0 &&
+                     (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y_out | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C, S), dim3(256), 0, st, dy, x, y_out, relu, scale, shift,
+                           save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW / 4), part);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C, S), dim3(256), 0, st, dy, x, y_out, relu, scale, shift,
+                           save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW), part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
                        (double)B * HW, dgamma, dbeta, coef);
-    const int64_t rows = (int64_t)B * C;
-    const int blocks = (int)(rows < 8192 ? rows : 8192);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dy, x, y_out, relu, scale, shift,
-                       save_mean, save_invstd, gamma, (const float*)coef, dx, dres, dres_accumulate, rows, C, HW);
+    if (vec) {
+        const int64_t nv = total / 4;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(nv)), dim3(256), 0, st, dy, x, y_out, relu, scale,
+                           shift, save_mean, save_invstd, gamma, (const float*)coef, dx, dres, dres_accumulate, nv,
+                           FastDiv::make(HW / 4), FastDiv::make(C));
+    } else {
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, dy, x, y_out, relu, scale,
+                           shift, save_mean, save_invstd, gamma, (const float*)coef, dx, dres, dres_accumulate, total,
+                           FastDiv::make(HW), FastDiv::make(C));
+    }
     SCAT_LAUNCH_CHECK("scat_bn_bwd");
     return SCAT_OK;
 }

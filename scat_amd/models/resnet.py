@@ -160,16 +160,14 @@ class _BackboneFn(torch.autograd.Function):
             g = dcur
             put(blk.conv3.weight, ops.conv2d_wgrad(dc3, c2, tuple(blk.conv3.weight.shape), 1, 0, s2.scale, s2.shift,
                                                    True, out=gbuf(blk.conv3.weight)))
-            da2 = ops.conv2d_dgrad(dc3, ops.conv2d_wt(blk.conv3.weight), tuple(c2.shape),
-                                   tuple(blk.conv3.weight.shape), 1, 0)
+            da2 = ops.conv2d_dgrad_w(dc3, blk.conv3.weight, tuple(c2.shape), 1, 0)
             del dc3
             dc2, dg, db = ops.bn_bwd(da2, c2, None, True, s2.scale, s2.shift, s2.mean, s2.invstd, blk.bn2.weight,
                                      gbuf(blk.bn2.weight), gbuf(blk.bn2.bias), dx=da2)
             put(blk.bn2.weight, dg), put(blk.bn2.bias, db)
             put(blk.conv2.weight, ops.conv2d_wgrad(dc2, c1, tuple(blk.conv2.weight.shape), blk.stride, 1, s1.scale,
                                                    s1.shift, True, out=gbuf(blk.conv2.weight)))
-            da1 = ops.conv2d_dgrad(dc2, ops.conv2d_wt(blk.conv2.weight), tuple(c1.shape),
-                                   tuple(blk.conv2.weight.shape), blk.stride, 1)
+            da1 = ops.conv2d_dgrad_w(dc2, blk.conv2.weight, tuple(c1.shape), blk.stride, 1)
             del dc2, da2
             dc1, dg, db = ops.bn_bwd(da1, c1, None, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight,
                                      gbuf(blk.bn1.weight), gbuf(blk.bn1.bias), dx=da1)
@@ -182,12 +180,11 @@ class _BackboneFn(torch.autograd.Function):
                                          gbuf(dsbn.weight), gbuf(dsbn.bias), dx=g)
                 put(dsbn.weight, dg), put(dsbn.bias, db)
                 put(dsw, ops.conv2d_wgrad(dcd, xin, tuple(dsw.shape), blk.stride, 0, out=gbuf(dsw)))
-                dxin = ops.conv2d_dgrad(dcd, ops.conv2d_wt(dsw), tuple(xin.shape), tuple(dsw.shape), blk.stride, 0)
+                dxin = ops.conv2d_dgrad_w(dcd, dsw, tuple(xin.shape), blk.stride, 0)
                 del dcd
             else:
                 dxin = g
-            dcur = ops.conv2d_dgrad(dc1, ops.conv2d_wt(blk.conv1.weight), tuple(xin.shape),
-                                    tuple(blk.conv1.weight.shape), 1, 0, out=dxin, accumulate=True)
+            dcur = ops.conv2d_dgrad_w(dc1, blk.conv1.weight, tuple(xin.shape), 1, 0, out=dxin, accumulate=True)
             del dc1, da1, g
             remaining -= 1
             if remaining == 0:

@@ -34,7 +34,7 @@ class _Conv2dFn(torch.autograd.Function):
         dy = _c(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_dgrad(dy, ops.conv2d_wt(w), tuple(x.shape), tuple(w.shape), stride, pad)
+            dx = ops.conv2d_dgrad_w(dy, w, tuple(x.shape), stride, pad)
         if ctx.needs_input_grad[1]:
             dw = ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad)
         if has_bias and ctx.needs_input_grad[2]:

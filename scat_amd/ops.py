@@ -92,6 +92,24 @@ def conv2d_dgrad(dy, wt, x_shape, w_shape, stride, pad, out=None, accumulate=Fal
     return dx
 
 
+def conv2d_dgrad_w(dy, w, x_shape, stride, pad, out=None, accumulate=False):
+    """Data gradient from the ORIGINAL weights: picks the parity-decomposed stride-2 kernels when they apply,
+    else transposes the weights and runs the generic gather."""
+    _chk(dy, w, out)
+    B, Cin, H, W = x_shape
+    Cout, _, KH, KW = w.shape
+    if stride == 2 and ((KH == 1 and pad == 0) or (KH == 3 and pad == 1)) and Cout % 4 == 0:
+        dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+        ws = workspace(lib().scat_conv2d_dgrad_s2_ws(Cin, Cout, KH, KW), dy.device, "wt")
+        OH, OW = conv_out_hw(H, W, KH, stride, pad)
+        _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_dgrad_s2, _p(dy), _p(w), _p(dx), B, Cin, H,
+              W, Cout, KH, KW, pad, int(accumulate), _p(ws), ws.numel(), _stream())
+        return dx
+    wt = conv2d_wt(w, out=workspace(4 * w.numel(), dy.device, "wt")[: 4 * w.numel()].view(torch.float32)
+                   .view(Cin, Cout * KH * KW))
+    return conv2d_dgrad(dy, wt, x_shape, tuple(w.shape), stride, pad, out=out, accumulate=accumulate)
+
+
 def conv2d_wgrad(dy, x, w_shape, stride, pad, in_scale=None, in_shift=None, in_relu=False, out=None):
     _chk(dy, x, in_scale, in_shift, out)
     B, Cin, H, W = x.shape

@@ -63,6 +63,11 @@ def test_conv_fwd_dgrad_wgrad(ops, cin, cout, k, s, p, H):
         base = g(t(4, "acc", tuple(x.shape)))
         dxa = ops.conv2d_dgrad(g(dy), wt, tuple(x.shape), tuple(w.shape), s, p, out=base.clone(), accumulate=True)
         assert rel_err(dxa, dx_ref + base.cpu().double()) < 2e-5
+        # from the original weights: stride-2 geometries take the parity-decomposed kernels
+        dxw = ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), s, p)
+        assert rel_err(dxw, dx_ref) < 2e-5
+        dxwa = ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), s, p, out=base.clone(), accumulate=True)
+        assert rel_err(dxwa, dx_ref + base.cpu().double()) < 2e-5
 
 
 def test_conv_fused_input_transform(ops):
@@ -81,6 +86,18 @@ def test_conv_fused_input_transform(ops):
         dw_ref = torch.nn.grad.conv2d_weight(a.double(), tuple(w.shape), dy.double(), stride=s, padding=1)
         dwg = ops.conv2d_wgrad(g(dy), g(x), tuple(w.shape), s, 1, g(sc), g(sh), True)
         assert rel_err(dwg, dw_ref) < 2e-5
+
+
+@pytest.mark.parametrize("H,W", [(13, 9), (8, 14), (7, 7)])
+def test_dgrad_s2_odd_sizes(ops, H, W):
+    """parity classes with ragged class grids (odd heights/widths)"""
+    for k, p in ((3, 1), (1, 0)):
+        x = t(50, "x", (2, 12, H, W)).requires_grad_(True)
+        w = t(51, "w", (20, 12, k, k), std=0.2).requires_grad_(True)
+        y = F.conv2d(x.double(), w.double(), stride=2, padding=p)
+        dy = t(52, "dy", tuple(y.shape))
+        (dx_ref,) = torch.autograd.grad(y, x, dy.double())
+        assert rel_err(ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 2, p), dx_ref) < 2e-5
 
 
 def test_conv_bias_and_edge_batches(ops):

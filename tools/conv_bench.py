@@ -65,7 +65,7 @@ def main():
                 if k == 7:
                     continue
                 dx = torch.empty_like(x)
-                fn = lambda: ops.conv2d_dgrad(dy, wt, tuple(x.shape), tuple(w.shape), s, p, out=dx)
+                fn = lambda: ops.conv2d_dgrad_w(dy, w, tuple(x.shape), s, p, out=dx)
             else:
                 dw = torch.empty_like(w)
                 fn = lambda: ops.conv2d_wgrad(dy, x, tuple(w.shape), s, p, out=dw)
