@@ -58,9 +58,9 @@ static void conv_gemm_tf(const MatDesc& da, const GatherDesc& db, const OutDesc&
         conv_gemm_cfg<KH, KW, D2, 1, false, TF>(KH == 7 ? pick_cfg(M, N) : C64x64, da, db, dc, M, N, K, st);
         return;
     }
-    if constexpr (KH == 1 && !D2) {
+    if constexpr (KH * KW <= 9 && !D2) {
         if (bv4) {
-            conv_gemm_cfg<1, 1, false, 4, true, TF>(pick_cfg(M, N), da, db, dc, M, N, K, st);
+            conv_gemm_cfg<KH, KW, false, 4, true, TF>(pick_cfg(M, N), da, db, dc, M, N, K, st);
             return;
         }
     }
@@ -102,12 +102,10 @@ static void dgrad_class_gemm(const MatDesc& da, const GatherDesc& db, const OutD
     const Cfg cfg = pick_cfg(M, N);
     static const char* const names[] = {"128x128", "128x64", "64x128", "64x64"};
     set_kernel_label("dgrad_s2_class%dx%d_%sx16%s", KHc, KWc, names[cfg], bv4 ? "_b4" : "");
-    if constexpr (KHc == 1 && KWc == 1) {
-        if (bv4) {
-            conv_gemm_cfg<1, 1, false, 4, true, false>(cfg, da, db, dc, M, N, K, st);
-            set_kernel_label("dgrad_s2_class1x1_%sx16_b4", names[cfg]);
-            return;
-        }
+    if (bv4) {
+        conv_gemm_cfg<KHc, KWc, false, 4, true, false>(cfg, da, db, dc, M, N, K, st);
+        set_kernel_label("dgrad_s2_class%dx%d_%sx16_b4", KHc, KWc, names[cfg]);
+        return;
     }
     conv_gemm_cfg<KHc, KWc, false, 4, false, false>(cfg, da, db, dc, M, N, K, st);
     set_kernel_label("dgrad_s2_class%dx%d_%sx16", KHc, KWc, names[cfg]);
@@ -145,9 +143,10 @@ extern "C" int scat_conv2d_fwd(const float* x, const float* w, const float* bias
     dc.p = y; dc.mode = 1; dc.I = Cout; dc.J = N; dc.C = Cout; dc.HW = OH * OW; dc.dHW = FastDiv::make(OH * OW);
     dc.bias = bias; dc.bias_mode = bias ? 1 : 0; dc.accumulate = 0; dc.n = (int64_t)B * Cout * OH * OW;
     hipStream_t st = (hipStream_t)stream;
-    const bool bv4 = KH == 1 && stride == 1 && pad == 0 && (H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    // 16-B pixel vectors: stride 1, output grid == input grid (1x1 pad 0 / 3x3 pad 1), plane a multiple of 4
+    const bool bv4 = stride == 1 && OH == H && OW == W && (H * W) % 4 == 0 && W >= 4 && ((uintptr_t)x & 15) == 0;
     if (KH == 1) conv_gemm<1, 1, false>(da, db, dc, Cout, N, K, bv4, st);
-    else if (KH == 3) conv_gemm<3, 3, false>(da, db, dc, Cout, N, K, false, st);
+    else if (KH == 3) conv_gemm<3, 3, false>(da, db, dc, Cout, N, K, bv4, st);
     else conv_gemm<7, 7, false>(da, db, dc, Cout, N, K, false, st);
     SCAT_LAUNCH_CHECK("scat_conv2d_fwd");
     return SCAT_OK;
@@ -177,10 +176,10 @@ extern "C" int scat_conv2d_dgrad(const float* dy, const float* wt, float* dx, in
     dc.p = dx; dc.mode = 1; dc.I = Cin; dc.J = N; dc.C = Cin; dc.HW = H * W; dc.dHW = FastDiv::make(H * W);
     dc.accumulate = accumulate; dc.n = (int64_t)B * Cin * H * W;
     hipStream_t st = (hipStream_t)stream;
-    const bool bv4 = KH == 1 && stride == 1 && pad == 0 && (H * W) % 4 == 0 && ((uintptr_t)dy & 15) == 0;
+    const bool bv4 = stride == 1 && OH == H && OW == W && (H * W) % 4 == 0 && W >= 4 && ((uintptr_t)dy & 15) == 0;
     if (stride == 1) {
         if (KH == 1) conv_gemm<1, 1, false>(da, db, dc, Cin, N, K, bv4, st);
-        else conv_gemm<3, 3, false>(da, db, dc, Cin, N, K, false, st);
+        else conv_gemm<3, 3, false>(da, db, dc, Cin, N, K, bv4, st);
     } else {
         if (KH == 1) conv_gemm<1, 1, true>(da, db, dc, Cin, N, K, false, st);
         else conv_gemm<3, 3, true>(da, db, dc, Cin, N, K, false, st);
@@ -231,12 +230,12 @@ extern "C" int scat_conv2d_dgrad_s2(const float* dy, const float* w, float* dx, 
             dc.p = dx; dc.mode = 2; dc.I = Cin; dc.J = N; dc.C = Cin; dc.HW = H * W; dc.W = W; dc.QW = QW;
             dc.sub_s = 2; dc.sub_y = py; dc.sub_x = px; dc.dQHW = FastDiv::make(QH * QW); dc.dQW = FastDiv::make(QW);
             dc.accumulate = accumulate; dc.n = (int64_t)B * Cin * H * W;
-            const bool bv4 = KKc == 1 && QH == OH && QW == OW && (OH * OW) % 4 == 0 && ((uintptr_t)dy & 15) == 0 &&
-                             ((py + pad) >> 1) == 0 && ((px + pad) >> 1) == 0;
+            // class grid == dy grid (even H, W): flat pixel index of the class maps 1:1 onto dy's plane
+            const bool bv4 = QH == OH && QW == OW && (OH * OW) % 4 == 0 && OW >= 4 && ((uintptr_t)dy & 15) == 0;
             if (KHc == 1 && KWc == 1) dgrad_class_gemm<1, 1>(da, db, dc, Cin, N, K, bv4, st);
-            else if (KHc == 1) dgrad_class_gemm<1, 2>(da, db, dc, Cin, N, K, false, st);
-            else if (KWc == 1) dgrad_class_gemm<2, 1>(da, db, dc, Cin, N, K, false, st);
-            else dgrad_class_gemm<2, 2>(da, db, dc, Cin, N, K, false, st);
+            else if (KHc == 1) dgrad_class_gemm<1, 2>(da, db, dc, Cin, N, K, bv4, st);
+            else if (KWc == 1) dgrad_class_gemm<2, 1>(da, db, dc, Cin, N, K, bv4, st);
+            else dgrad_class_gemm<2, 2>(da, db, dc, Cin, N, K, bv4, st);
         }
     }
     SCAT_LAUNCH_CHECK("scat_conv2d_dgrad_s2");

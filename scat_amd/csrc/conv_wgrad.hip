@@ -4,11 +4,19 @@
 
 namespace scat {
 
+// out[e] (+)= sum_z slab[z][e]: 8 independent loads in flight per thread, combined in a fixed order
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int splits,
                                      int accumulate) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         float s = accumulate ? out[e] : 0.f;
-        for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * n + e];
+        int z = 0;
+        for (; z + 8 <= splits; z += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = slab[(int64_t)(z + q) * n + e];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; z < splits; ++z) s += slab[(int64_t)z * n + e];
         out[e] = s;
     }
 }
@@ -98,13 +106,15 @@ extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int
     dc.mode = 0; dc.si = p.N; dc.sj = 1; dc.sz = (int64_t)p.M * p.N; dc.I = p.M; dc.J = p.N; dc.n = (int64_t)p.M * p.N;
     hipStream_t st = (hipStream_t)stream;
     const bool av4 = (OH * OW) % 4 == 0 && ((uintptr_t)dy & 15) == 0;
-    const bool bv4 = KH == 1 && stride == 1 && pad == 0 && (H * W) % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    const bool bv4 = KH <= 3 && stride == 1 && OH == H && OW == W && (H * W) % 4 == 0 && W >= 4 &&
+                     ((uintptr_t)x & 15) == 0;
     if (KH == 1) {
         if (av4 && bv4) wgrad_gemm<1, 1, true, true>(p, da, db, dc, st);
         else if (av4) wgrad_gemm<1, 1, true, false>(p, da, db, dc, st);
         else wgrad_gemm<1, 1, false, false>(p, da, db, dc, st);
     } else if (KH == 3) {
-        if (av4) wgrad_gemm<3, 3, true, false>(p, da, db, dc, st);
+        if (av4 && bv4) wgrad_gemm<3, 3, true, true>(p, da, db, dc, st);
+        else if (av4) wgrad_gemm<3, 3, true, false>(p, da, db, dc, st);
         else wgrad_gemm<3, 3, false, false>(p, da, db, dc, st);
     } else {
         if (av4) wgrad_gemm<7, 7, true, false>(p, da, db, dc, st);
@@ -113,8 +123,8 @@ extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int
     SCAT_LAUNCH_CHECK("scat_conv2d_wgrad");
     if (p.splits > 1) {
         int64_t n = (int64_t)p.M * p.N;
-        int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, n, p.splits, 0);
+        int blocks = (int)((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(64), 0, st, (const float*)ws, dw, n, p.splits, 0);
         SCAT_LAUNCH_CHECK("scat_conv2d_wgrad(reduce)");
     }
     return SCAT_OK;

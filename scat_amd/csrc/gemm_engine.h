@@ -144,20 +144,23 @@ struct MatLoader {
 
 // Conv-arithmetic loader. KH,KW compile-time so tap decode is mul-shift. D2 = divisor 2 (data-gradient
 // of a stride-2 conv: only taps of matching parity contribute).  PIXK: the pixel index is the
-// contraction index (weight gradient).  V4: 16-B loads along 4 consecutive pixels — only for
-// KH=KW=1, stride 1, no padding, (PH*PW) % 4 == 0.
+// contraction index (weight gradient).  V4: 16-B loads along 4 consecutive pixels of the flat NCHW
+// plane — stride-1 arithmetic only (a == 1), (PH*PW) % 4 == 0.  For KH*KW > 1 the vector is shifted by
+// the tap offset (4-B aligned dwordx4) and each of the 4 pixels carries its own tap-validity mask.
 // TF: the fused per-channel scale/shift(+ReLU) input transform is compiled in.
 template <int BI, int BK, int KH, int KW, bool D2, bool PIXK, bool V4 = false, bool TF = false>
 struct GatherLoader {
     static constexpr int KK = KH * KW;
     static constexpr int NE = BI * BK / NT;
     static constexpr int NV = V4 ? NE / 4 : NE;
-    static_assert(!V4 || (KK == 1 && !D2), "V4 is the 1x1 stride-1 path");
+    static_assert(!V4 || (KK <= 9 && !D2), "V4 is a stride-1 path for up to 3x3 taps");
+    static constexpr bool V4M = V4 && KK > 1;     // multi-tap vector path: per-pixel masks
     using Desc = GatherDesc;
     float v[NE];
-    unsigned okbits;
+    unsigned okbits;                              // V4M: 4 bits per element (one per pixel)
     int pixoff;
     uint64_t mask;
+    uint32_t pm[V4M ? 4 : 1];                     // V4M: tap mask of each of the 4 pixels
     // PIXK: ct-side state fixed per tile (offset, tap, fused-transform constants)
     int ctoff[PIXK ? NV : 1];
     int cttap[PIXK ? NV : 1];
@@ -200,6 +203,49 @@ struct GatherLoader {
         pixoff = (int)n * d.C * d.H * d.W + (D2 ? ((ty0 >> 1) * d.W + (tx0 >> 1)) : (ty0 * d.W + tx0));
     }
 
+    // V4M: tap masks of 4 consecutive pixels starting at pix (same image: (PH*PW) % 4 == 0, pix % 4 == 0)
+    __device__ __forceinline__ void decode4(const GatherDesc& d, int pix) {
+        pm[0] = pm[V4M ? 1 : 0] = pm[V4M ? 2 : 0] = pm[V4M ? 3 : 0] = 0;
+        pixoff = 0;
+        if (pix >= d.npix) return;
+        uint32_t n = d.dPHW.div((uint32_t)pix);
+        uint32_t r = pix - n * (d.PH * d.PW);
+        int y = (int)d.dPW.div(r);
+        int x = (int)r - y * d.PW;
+        pixoff = (int)n * d.C * d.H * d.W + (y + d.c0) * d.W + (x + d.c0x);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t rowm = 0, colm = 0, m = 0;
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) rowm |= ((unsigned)(y + d.c0 + kh * d.b) < (unsigned)d.H ? 1u : 0u) << kh;
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) colm |= ((unsigned)(x + d.c0x + kw * d.b) < (unsigned)d.W ? 1u : 0u) << kw;
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh)
+                if ((rowm >> kh) & 1u) m |= colm << (kh * KW);
+            pm[V4M ? q : 0] = m;
+            if (++x == d.PW) { x = 0; ++y; }
+        }
+    }
+    // one shifted 16-B load; vectors that would start before / end after the tensor (first and last pixel
+    // group of the whole tensor only) fall back to 4 bounds-checked scalar loads
+    __device__ __forceinline__ void vload_shifted(const GatherDesc& d, int r, int elem_off, uint32_t bits4) {
+        const int boff = elem_off * 4;
+        if (bits4 == 0) {
+            v[4 * r] = v[4 * r + 1] = v[4 * r + 2] = v[4 * r + 3] = 0.f;
+        } else if (boff >= 0 && (int64_t)boff + 16 <= d.n * 4) {
+            float4 t = bload4(rs, boff);
+            v[4 * r] = t.x; v[4 * r + 1] = t.y; v[4 * r + 2] = t.z; v[4 * r + 3] = t.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[4 * r + q] = bload(rs, ((bits4 >> q) & 1u) ? boff + 4 * q : OOB);
+        }
+    }
+    __device__ __forceinline__ uint32_t bits_for_tap(int tap) const {
+        return ((pm[0] >> tap) & 1u) | (((pm[V4M ? 1 : 0] >> tap) & 1u) << 1) | (((pm[V4M ? 2 : 0] >> tap) & 1u) << 2) |
+               (((pm[V4M ? 3 : 0] >> tap) & 1u) << 3);
+    }
+
     // thread -> (pixel-side index, ct-side index) inside the tile, element r
     static constexpr int PV = V4 ? 4 : 1;                                   // pixels per load
     static constexpr int PT = (PIXK ? BK : BI) / PV;                        // threads along the pixel dim
@@ -212,7 +258,8 @@ struct GatherLoader {
 #pragma unroll
         for (int r = 0; r < NE; ++r) v[r] = 0.f;
         if (!PIXK) {
-            decode_pix(d, i0 + pix_l());
+            if constexpr (V4M) decode4(d, i0 + pix_l());
+            else decode_pix(d, i0 + pix_l());
         } else {
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
@@ -236,6 +283,17 @@ struct GatherLoader {
                 // make that visible so the tap decode and the fused-transform constants go scalar
                 int ct = k0 + (PT >= 64 ? __builtin_amdgcn_readfirstlane(ct_l(r)) : ct_l(r));
                 int c = ct / KK, tap = ct - c * KK;
+                if constexpr (V4M) {
+                    const uint32_t bits4 = ct < kend ? bits_for_tap(tap) : 0u;
+                    vload_shifted(d, r, pixoff + c * d.H * d.W + tap_off(d, tap), bits4);
+                    okbits |= bits4 << (4 * r);
+                    if constexpr (TF) {
+                        int cc = ct < kend ? c : 0;
+                        rsc[r] = d.scale[cc];
+                        rsh[r] = d.shift[cc];
+                    }
+                    continue;
+                }
                 bool ok = (ct < kend) && ((mask >> tap) & 1ull);
                 int off = ok ? (pixoff + c * d.H * d.W + tap_off(d, tap)) * 4 : OOB;
                 if (V4) {
@@ -253,6 +311,16 @@ struct GatherLoader {
             }
         } else {
             int pix = k0 + pix_l();
+            if constexpr (V4M) {
+                decode4(d, pix < kend ? pix : d.npix);
+#pragma unroll
+                for (int r = 0; r < NV; ++r) {
+                    const uint32_t bits4 = cttap[r] >= 0 ? bits_for_tap(cttap[r] & 15) : 0u;
+                    vload_shifted(d, r, pixoff + ctoff[r], bits4);
+                    okbits |= bits4 << (4 * r);
+                }
+                return;
+            }
             decode_pix(d, pix < kend ? pix : d.npix);
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
@@ -272,17 +340,19 @@ struct GatherLoader {
     __device__ __forceinline__ void store(const GatherDesc& d, float* lds) const {
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            const bool ok = (okbits >> r) & 1u;
             float t[PV];
 #pragma unroll
             for (int q = 0; q < PV; ++q) {
+                const bool ok = V4M ? (okbits >> (4 * r + q)) & 1u : (okbits >> r) & 1u;
                 float x = v[PV * r + q];
                 if constexpr (TF) {
                     x = fmaf(x, PIXK ? csc[r] : rsc[r], PIXK ? csh[r] : rsh[r]);
                     x = d.relu ? fmaxf(x, 0.f) : x;
-                    x = ok ? x : 0.f;      // padding stays zero after the transform
                 }
-                t[q] = x;                  // without a transform the bounds-checked load already gave 0
+                // a shifted vector reads real neighbours where the conv wants padding: mask per pixel;
+                // otherwise the bounds-checked load already returned 0 (only the transform needs re-masking)
+                if constexpr (TF || V4M) x = ok ? x : 0.f;
+                t[q] = x;
             }
             const int pl = pix_l(), cl = ct_l(r);
             if (!PIXK) {          // tile[k = ct][i = pixel]: pixels contiguous

@@ -291,23 +291,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-// out[j] (+)= sum_i x[i*cols + j]; block = 64 columns x 16 row lanes, fixed order
+// out[j] (+)= sum_i x[i*cols + j]; block = 16 columns x 64 row lanes (many blocks, short loops, 8 loads in
+// flight per thread), fixed summation order
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows,
                                                       int cols, int accumulate) {
-    __shared__ float sh[16][65];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + tx;
+    __shared__ float sh[64][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + tx;
     float s = 0.f;
-    if (j < cols)
-        for (int i = ty; i < rows; i += 16) s += x[(int64_t)i * cols + j];
+    if (j < cols) {
+        int i = ty;
+        for (; i + 7 * 64 < rows; i += 8 * 64) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = x[(int64_t)(i + q * 64) * cols + j];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; i < rows; i += 64) s += x[(int64_t)i * cols + j];
+    }
     sh[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && j < cols) {
-        float r = accumulate ? out[j] : 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) r += sh[k][tx];
-        out[j] = r;
+    for (int half = 32; half > 0; half >>= 1) {
+        if (ty < half) sh[ty][tx] += sh[ty + half][tx];
+        __syncthreads();
     }
+    if (ty == 0 && j < cols) out[j] = (accumulate ? out[j] : 0.f) + sh[0][tx];
 }
 
 }  // namespace scat
@@ -438,15 +447,15 @@ extern "C" int scat_layernorm_bwd(const float* dy, const float* x, const float* 
     float* t = (float*)ws;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, t, rows,
                        dim);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim, 64)), dim3(1024), 0, st, (const float*)t, dgamma, rows, dim, 0);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim, 64)), dim3(1024), 0, st, dy, dbeta, rows, dim, 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim, 16)), dim3(1024), 0, st, (const float*)t, dgamma, rows, dim, 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim, 16)), dim3(1024), 0, st, dy, dbeta, rows, dim, 0);
     SCAT_LAUNCH_CHECK("scat_layernorm_bwd");
     return SCAT_OK;
 }
 
 extern "C" int scat_colsum(const float* x, float* out, int rows, int cols, int accumulate, void* stream) {
     SCAT_REQUIRE(x && out && rows > 0 && cols > 0, SCAT_E_ARG, "scat_colsum: bad argument");
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, (hipStream_t)stream, x, out, rows, cols,
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 16)), dim3(1024), 0, (hipStream_t)stream, x, out, rows, cols,
                        accumulate);
     SCAT_LAUNCH_CHECK("scat_colsum");
     return SCAT_OK;

@@ -38,17 +38,17 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     }
 }
 
-// gather form (no atomics): an input pixel sums the windows whose arg-max it is
+// gather form (no atomics): an input pixel sums the windows whose arg-max it is.
+// grid.y = (n,c) plane, threads sweep the plane: no integer divisions by runtime sizes except one per pixel row.
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
                                                           const int8_t* __restrict__ idx, float* __restrict__ dx,
-                                                          int64_t total, int H, int W, int OH, int OW) {
-    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
-        int ix = e % W;
-        int64_t r = e / W;
-        int iy = r % H;
-        int64_t nc = r / H;
-        const float* g = dy + nc * OH * OW;
-        const int8_t* id = idx + nc * OH * OW;
+                                                          int H, int W, int OH, int OW) {
+    const int64_t nc = blockIdx.y;
+    const float* g = dy + nc * OH * OW;
+    const int8_t* id = idx + nc * OH * OW;
+    float* o = dx + nc * H * W;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < H * W; e += gridDim.x * 256) {
+        const int iy = e / W, ix = e - iy * W;
         float s = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
@@ -58,11 +58,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
             for (int kw = 0; kw < 3; ++kw) {
                 int u = ix + 1 - kw;
                 if (u < 0 || (u & 1) || (u >> 1) >= OW) continue;
-                int o = (t >> 1) * OW + (u >> 1);
-                if (id[o] == kh * 3 + kw) s += g[o];
+                int q = (t >> 1) * OW + (u >> 1);
+                if (id[q] == kh * 3 + kw) s += g[q];
             }
         }
-        dx[e] = s;
+        o[e] = s;
     }
 }
 
@@ -117,9 +117,8 @@ extern "C" int scat_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* 
     SCAT_REQUIRE(dy && idx && dx, SCAT_E_ARG, "scat_maxpool3x3s2_bwd: null pointer");
     SCAT_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, SCAT_E_SHAPE, "scat_maxpool3x3s2_bwd: non-positive dimension");
     int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    int64_t total = (int64_t)B * C * H * W;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx,
-                       total, H, W, OH, OW);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(cdiv((int64_t)H * W, 256 * 4), B * C), dim3(256), 0,
+                       (hipStream_t)stream, dy, idx, dx, H, W, OH, OW);
     SCAT_LAUNCH_CHECK("scat_maxpool3x3s2_bwd");
     return SCAT_OK;
 }
