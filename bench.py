@@ -163,7 +163,8 @@ def main():
     note(f"{a.steps} steps in {dt:.3f} s = {a.batch * world * a.steps / dt:.1f} img/s; roofline + CPU baseline legs")
 
     roof, table = (None, {})
-    if rank == 0 and not a.no_roofline:
+    if not a.no_roofline:
+        # every rank runs the instrumented step (it contains the gradient all-reduces); rank 0 reports
         roof, table = dominant_kernel_roofline(ts, x, lab)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -13,8 +13,8 @@ static Cfg pick_cfg(int M, int N) {
     if (M > 64 && tiles(128, 128) >= 384) return C128x128;
     if (M > 64 && tiles(128, 64) >= 384) return C128x64;
     if (M <= 64) return tiles(64, 128) >= 384 ? C64x128 : C64x64;
-    if (tiles(128, 64) >= 256) return C128x64;
-    return C64x64;
+    if (tiles(128, 64) >= 400) return C128x64;
+    return C64x64;   // under-filled grids (layer4: N = 4704): more, smaller workgroups
 }
 
 // forward / data-gradient share one kernel family: A = weights (K contiguous), B = gather, pixel = column

@@ -72,6 +72,7 @@ class GradBuckets:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self._pending = []
         self._head_sent = False
+        self._avg_ok = True
         backbone = getattr(model, "main_encoder", None)
         if backbone is not None:
             backbone._grad_sink = self
@@ -91,9 +92,13 @@ class GradBuckets:
         if self.world <= 1:
             return
         backend = dist.get_backend(self.pg)
-        if backend == "nccl":   # RCCL on ROCm
-            self._pending.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
-        else:                   # gloo (CPU tests): no AVG
+        if backend == "nccl" and self._avg_ok:   # RCCL on ROCm
+            try:
+                self._pending.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
+                return
+            except RuntimeError:
+                self._avg_ok = False             # older RCCL without AVG: sum, then scale
+        if True:                # gloo (CPU tests) / fallback: SUM then 1/N
             self._pending.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), t))
 
     def begin_backbone(self):
@@ -148,11 +153,14 @@ def init_distributed():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
-        torch.cuda.set_device(local)   # before model construction: the ctor calls .cuda() (hand_net.py:321)
+        # before model construction: the ctor calls .cuda() (hand_net.py:321).  (modulo: rehearsing N ranks on a
+        # 1-GPU box with the gloo backend maps every rank onto the one device)
+        local = local % torch.cuda.device_count()
+        torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("SCAT_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local)
