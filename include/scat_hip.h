@@ -129,14 +129,23 @@ int scat_tokens_fwd(const float* x, const float* pe, const float* mask_token, co
 int scat_tokens_bwd(const float* dy, const int32_t* masked, int nmasked, float* dx, float* dmask_token, int B, int T,
                     int D, void* stream);
 
+/* nearest-neighbour upsample by an integer factor (models/hrnet.py:107) and mean over tokens
+ * (hand_net.py:203 feat.mean(dim=1); vision_performer.py:108) */
+int scat_upsample_nearest_fwd(const float* x, float* y, int B, int C, int H, int W, int factor, void* stream);
+int scat_upsample_nearest_bwd(const float* dy, float* dx, int B, int C, int H, int W, int factor, void* stream);
+int scat_token_mean_fwd(const float* x, float* y, int B, int T, int D, void* stream);
+int scat_token_mean_bwd(const float* dy, float* dx, int B, int T, int D, void* stream);
+
 /* ---- head: regressor loop + root-relative (hand_net.py:379-393) ----
- * pred0[b] = mean[66]; pred0[:,3:] += feat_out[b,63]; iter x: pred += [feat1024,pred]·W^T + bias; joints -= joint1.
- * preds[(iters+1),B,66] keeps every iterate for backward; out[B,66]. */
+ * pred0[b] = mean[P]; pred0[:,3:] += feat_out[b,P-3] (if feat_out); iter x: pred += [feat,pred]·W^T + bias;
+ * root_relative: joints -= joint1.  preds[(iters+1),B,P] keeps every iterate for backward; out[B,P].
+ * The same loop is the HRNet wrapper's head (hand_net.py:206-211: F=196, P=61, no offsets, not root-relative)
+ * and ViP's (vision_performer.py:112-115). */
 int scat_regressor_fwd(const float* feat, const float* feat_out, const float* mean, const float* w, const float* bias,
-                       float* preds, float* out, int B, int F, int P, int iters, void* stream);
+                       float* preds, float* out, int B, int F, int P, int iters, int root_relative, void* stream);
 int scat_regressor_bwd(const float* dout, const float* feat, const float* preds, const float* w, float* dfeat,
-                       float* dfeat_out, float* dw, float* dbias, int B, int F, int P, int iters, void* ws,
-                       int64_t ws_bytes, void* stream);
+                       float* dfeat_out, float* dw, float* dbias, int B, int F, int P, int iters, int root_relative,
+                       void* ws, int64_t ws_bytes, void* stream);
 int64_t scat_regressor_bwd_ws(int B, int F, int P, int iters);
 
 /* ---- loss: train.py:165-203 (orthographic projection *112+112, MSE 3-D, L1 2-D) ----

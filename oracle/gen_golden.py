@@ -238,7 +238,48 @@ def g_performer():
     np.savez(os.path.join(GOLD, "performer.npz"), **out)
 
 
-ALL = {"vt": g_vt, "bottleneck": g_bottleneck, "resnet": g_resnet, "encoder": g_encoder,
+def g_hrnet():
+    """G8b: HRNet(c=32, nof_joints=128) B=1 224x224 train-mode fwd + bwd (reference modules), and the wrapper
+    (HRNet c=24 -> view 512x28x28 -> conv3x3/2 -> tokens -> vit.Transformer -> mean -> 3x Linear(257->61))."""
+    from models import hrnet as H
+    from models import vit as V
+    from models.hand_net import EncoderTransformerHRNet
+
+    net = H.HRNet(c=32, nof_joints=128, bn_momentum=0.1)
+    load_strict(net, synth.to_torch(synth.fill_state(101, net.state_dict())))
+    net.train()
+    x = T(synth.images(102, 1))
+    y = net(x)
+    (y * T(synth.normal_like(103, "cot", tuple(y.shape)))).sum().backward()
+    out = {"y": digest(y, 64), "y_chsum": y.detach().double().sum(dim=(0, 2, 3)).numpy(),
+           "y_head": y[0, :4, :4, :8].detach().numpy(),
+           "stage4.2.bn.rm": net.stage4[2].branches[0][3].bn2.running_mean.numpy().copy()}
+    for k in ("conv1.weight", "final_layer.weight", "final_layer.bias", "stage3.1.fuse_layers.0.2.0.weight",
+              "stage4.2.fuse_layers.0.3.1.weight", "stage2.0.branches.1.2.conv1.weight", "transition2.2.0.0.weight",
+              "layer1.0.downsample.0.weight"):
+        out["g:" + k] = digest(dict(net.named_parameters())[k].grad, 8)
+    net.eval()
+    with torch.no_grad():
+        out["y_eval"] = digest(net(x), 64)
+    # wrapper (reference class with the working transformer swapped in)
+    w = EncoderTransformerHRNet(opt_ns(), T(synth.mean_params(104, 61)))
+    w.transformer = V.Transformer(196, 3, 8, 64, 392, 0.0)
+    load_strict(w, synth.to_torch(synth.hrnet_wrapper_state(105, w.state_dict())))
+    w.train()
+    random.seed(7)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):   # the reference prints feat.shape every call
+        p = w(T(synth.images(106, 2)))
+    p.square().sum().backward()
+    out["wrap:pred"] = p.detach().numpy()
+    out["wrap:g:regressor.0.weight"] = digest(w.regressor[0].weight.grad, 8)
+    out["wrap:g:mask_token"] = digest(w.mask_token.grad, 8)
+    out["wrap:g:conv1x1_channel_reduction.weight"] = digest(w.conv1x1_channel_reduction.weight.grad, 8)
+    out["wrap:g:transformer.layers.0.0.fn.to_qkv.weight"] = digest(w.transformer.layers[0][0].fn.to_qkv.weight.grad, 8)
+    np.savez(os.path.join(GOLD, "hrnet.npz"), **out)
+
+
+ALL = {"hrnet": g_hrnet, "vt": g_vt, "bottleneck": g_bottleneck, "resnet": g_resnet, "encoder": g_encoder,
        "trainstep": g_trainstep, "vit": g_vit, "performer": g_performer}
 
 if __name__ == "__main__":

@@ -77,6 +77,97 @@ def resnet_forward(sd, x, prefix="", training=True):
 
 
 # --------------------------------------------------------------------------
+# HRNet backbone — models/hrnet.py
+# --------------------------------------------------------------------------
+
+def _cbn(sd, kc, kb, x, training, stride=1, pad=1, relu=False):
+    y = batch_norm(sd, kb, F.conv2d(x, sd[kc + ".weight"], stride=stride, padding=pad), training)
+    return F.relu(y) if relu else y
+
+
+def hr_basic_block(sd, key, x, training):
+    """BasicBlock.forward, models/hrnet.py:61-77."""
+    out = _cbn(sd, key + ".conv1", key + ".bn1", x, training, relu=True)
+    out = _cbn(sd, key + ".conv2", key + ".bn2", out, training)
+    return F.relu(out + x)
+
+
+def hr_stage_module(sd, key, xs, stage, out_branches, training):
+    """StageModule.forward, models/hrnet.py:128-144 (fuse layers built at :99-124)."""
+    xs = list(xs)
+    for i in range(stage):
+        for b in range(4):
+            xs[i] = hr_basic_block(sd, f"{key}.branches.{i}.{b}", xs[i], training)
+    fused = []
+    for i in range(out_branches):
+        acc = None
+        for j in range(stage):
+            fk = f"{key}.fuse_layers.{i}.{j}"
+            if i == j:
+                t = xs[j]
+            elif i < j:   # 1x1 conv + BN + nearest upsample by 2**(j-i)
+                t = _cbn(sd, fk + ".0", fk + ".1", xs[j], training, pad=0)
+                t = F.interpolate(t, scale_factor=float(2 ** (j - i)), mode="nearest")
+            else:         # chain of stride-2 3x3 convs, ReLU on all but the last
+                t = xs[j]
+                for k in range(i - j):
+                    t = _cbn(sd, f"{fk}.{k}.0", f"{fk}.{k}.1", t, training, stride=2, relu=(k < i - j - 1))
+            acc = t if acc is None else acc + t
+        fused.append(F.relu(acc))
+    return fused
+
+
+def hrnet_forward(sd, x, prefix="", training=True):
+    """HRNet.forward, models/hrnet.py:230-261 -> [B,nof_joints,56,56]."""
+    p = prefix
+    x = _cbn(sd, p + "conv1", p + "bn1", x, training, stride=2, relu=True)
+    x = _cbn(sd, p + "conv2", p + "bn2", x, training, stride=2, relu=True)
+    for b in range(4):   # layer1: Bottlenecks (hrnet.py:10-45), first with a 1x1 downsample
+        k = f"{p}layer1.{b}"
+        out = _cbn(sd, k + ".conv1", k + ".bn1", x, training, pad=0, relu=True)
+        out = _cbn(sd, k + ".conv2", k + ".bn2", out, training, relu=True)
+        out = _cbn(sd, k + ".conv3", k + ".bn3", out, training, pad=0)
+        res = _cbn(sd, k + ".downsample.0", k + ".downsample.1", x, training, pad=0) \
+            if (k + ".downsample.0.weight") in sd else x
+        x = F.relu(out + res)
+    xs = [_cbn(sd, p + "transition1.0.0", p + "transition1.0.1", x, training, relu=True),
+          _cbn(sd, p + "transition1.1.0.0", p + "transition1.1.0.1", x, training, stride=2, relu=True)]
+    xs = hr_stage_module(sd, p + "stage2.0", xs, 2, 2, training)
+    xs = [xs[0], xs[1], _cbn(sd, p + "transition2.2.0.0", p + "transition2.2.0.1", xs[-1], training, stride=2,
+                             relu=True)]
+    for m in range(4):
+        xs = hr_stage_module(sd, f"{p}stage3.{m}", xs, 3, 3, training)
+    xs = [xs[0], xs[1], xs[2], _cbn(sd, p + "transition3.3.0.0", p + "transition3.3.0.1", xs[-1], training,
+                                    stride=2, relu=True)]
+    xs = hr_stage_module(sd, p + "stage4.0", xs, 4, 4, training)
+    xs = hr_stage_module(sd, p + "stage4.1", xs, 4, 4, training)
+    xs = hr_stage_module(sd, p + "stage4.2", xs, 4, 1, training)
+    return F.conv2d(xs[0], sd[p + "final_layer.weight"], sd[p + "final_layer.bias"])
+
+
+def encoder_transformer_hrnet_forward(sd, mean_params, x, heads=8, depth=3, iteration=3, pos_embed=True,
+                                      mask_rate=0.2, training=True, masked=None):
+    """EncoderTransformerHRNet.forward, models/hand_net.py:176-213, with the dim-preserving
+    models/vit.py transformer (the only wiring in which the wrapper's shapes agree)."""
+    f = hrnet_forward(sd, x, "main_encoder.", training)
+    b = f.size(0)
+    feat = F.conv2d(f.reshape(b, 512, 28, 28), sd["conv1x1_channel_reduction.weight"], stride=2, padding=1)
+    feat = feat.reshape(b, 128, -1)
+    if pos_embed:
+        feat = feat + sd["positionalEncoding.pe"][: feat.size(0)]
+    if masked is None:
+        masked = mask_indices(mask_rate, 128)
+    if len(masked):
+        feat = feat.clone()
+        feat[:, masked, :] = sd["mask_token"]
+    feat = vit_forward(sd, feat, "transformer.", depth, heads).mean(dim=1)
+    pred = mean_params.repeat(b, 1)
+    for _ in range(iteration):
+        pred = pred + F.linear(torch.cat([feat, pred], dim=-1), sd["regressor.0.weight"], sd["regressor.0.bias"])
+    return pred
+
+
+# --------------------------------------------------------------------------
 # token mixers
 # --------------------------------------------------------------------------
 

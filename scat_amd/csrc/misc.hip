@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void regressor_fwd_kernel(const float* __restr
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ preds,
-                                                            float* __restrict__ out, int B, int F, int P, int iters) {
+                                                            float* __restrict__ out, int B, int F, int P, int iters,
+                                                            int root_rel) {
     __shared__ float base[128], pred[128], upd[128];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ldw = F + P;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void regressor_fwd_kernel(const float* __restr
     }
     if (tid < P) {
         float v = mean[tid];
-        if (tid >= 3) v += feat_out[(int64_t)b * (P - 3) + tid - 3];
+        if (feat_out && tid >= 3) v += feat_out[(int64_t)b * (P - 3) + tid - 3];
         pred[tid] = v;
         preds[((int64_t)0 * B + b) * P + tid] = v;
     }
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void regressor_fwd_kernel(const float* __restr
     }
     if (tid < P) {
         float v = pred[tid];
-        if (tid >= 3) v -= pred[3 + 3 + (tid - 3) % 3];   // root joint 1 (hand_net.py:389-391)
+        if (root_rel && tid >= 3) v -= pred[3 + 3 + (tid - 3) % 3];   // root joint 1 (hand_net.py:389-391)
         out[(int64_t)b * P + tid] = v;
     }
 }
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(128) void regressor_bwd_delta_kernel(const float* _
                                                                   float* __restrict__ deltas,
                                                                   float* __restrict__ dsum,
                                                                   float* __restrict__ dfeat_out, int B, int F, int P,
-                                                                  int iters) {
+                                                                  int iters, int root_rel) {
     __shared__ float g[128], gn[128];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int ldw = F + P;
@@ -156,11 +157,11 @@ __global__ __launch_bounds__(128) void regressor_bwd_delta_kernel(const float* _
     __syncthreads();
     // root-relative backward: joint 1 receives minus the sum over joints, per coordinate
     float adj = 0.f;
-    if (tid >= 6 && tid < 9) {
+    if (root_rel && tid >= 6 && tid < 9) {
         for (int k = 0; k < (P - 3) / 3; ++k) adj += g[3 + 3 * k + (tid - 6)];
     }
     __syncthreads();
-    if (tid >= 6 && tid < 9) g[tid] -= adj;
+    if (root_rel && tid >= 6 && tid < 9) g[tid] -= adj;
     __syncthreads();
     float ds = 0.f;
     for (int it = iters - 1; it >= 0; --it) {
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(128) void regressor_bwd_delta_kernel(const float* _
     }
     if (tid < P) {
         dsum[(int64_t)b * P + tid] = ds;
-        if (tid >= 3) dfeat_out[(int64_t)b * (P - 3) + tid - 3] = g[tid];
+        if (dfeat_out && tid >= 3) dfeat_out[(int64_t)b * (P - 3) + tid - 3] = g[tid];
     }
 }
 
@@ -220,6 +221,52 @@ __global__ __launch_bounds__(256) void regressor_bwd_feat_kernel(const float* __
     float s = 0.f;
     for (int j = 0; j < P; ++j) s = fmaf(dsum[(int64_t)b * P + j], w[(int64_t)j * ldw + f], s);
     dfeat[e] = s;
+}
+
+// ---------------------------------------------------------------- nearest upsample (hrnet.py:107) / token mean
+
+__global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total, int H, int W,
+                                    int f) {
+    const int OW = W * f, OH = H * f;
+    GRID_STRIDE(e, total) {
+        int ox = e % OW;
+        int64_t r = e / OW;
+        int oy = r % OH;
+        int64_t nc = r / OH;
+        y[e] = x[(nc * H + oy / f) * W + ox / f];
+    }
+}
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t total, int H, int W,
+                                    int f) {
+    const int OW = W * f;
+    GRID_STRIDE(e, total) {
+        int x = e % W;
+        int64_t r = e / W;
+        int y = r % H;
+        int64_t nc = r / H;
+        const float* p = dy + (nc * H * f + (int64_t)y * f) * OW + x * f;
+        float s = 0.f;
+        for (int a = 0; a < f; ++a)
+            for (int b = 0; b < f; ++b) s += p[a * OW + b];
+        dx[e] = s;
+    }
+}
+// y[b,d] = mean_t x[b,t,d]
+__global__ void tokmean_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total, int T, int D) {
+    GRID_STRIDE(e, total) {
+        int d = e % D;
+        int64_t b = e / D;
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += x[(b * T + t) * D + d];
+        y[e] = s / T;
+    }
+}
+__global__ void tokmean_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t total, int T, int D) {
+    GRID_STRIDE(e, total) {
+        int d = e % D;
+        int64_t b = e / ((int64_t)T * D);
+        dx[e] = dy[b * D + d] / T;
+    }
 }
 
 // ---------------------------------------------------------------- loss (train.py:165-203)
@@ -339,6 +386,39 @@ extern "C" int scat_axpy(const float* a, const float* b, float alpha, float* y, 
     EW_ENTRY(scat_axpy, axpy_kernel, a, b, alpha, y, n)
 }
 
+extern "C" int scat_upsample_nearest_fwd(const float* x, float* y, int B, int C, int H, int W, int factor,
+                                         void* stream) {
+    SCAT_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && factor >= 1, SCAT_E_ARG,
+                 "scat_upsample_nearest_fwd: bad argument");
+    int64_t n = (int64_t)B * C * H * W * factor * factor;
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, H, W, factor);
+    SCAT_LAUNCH_CHECK("scat_upsample_nearest_fwd");
+    return SCAT_OK;
+}
+extern "C" int scat_upsample_nearest_bwd(const float* dy, float* dx, int B, int C, int H, int W, int factor,
+                                         void* stream) {
+    SCAT_REQUIRE(dy && dx && B > 0 && C > 0 && H > 0 && W > 0 && factor >= 1, SCAT_E_ARG,
+                 "scat_upsample_nearest_bwd: bad argument");
+    int64_t n = (int64_t)B * C * H * W;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, H, W, factor);
+    SCAT_LAUNCH_CHECK("scat_upsample_nearest_bwd");
+    return SCAT_OK;
+}
+extern "C" int scat_token_mean_fwd(const float* x, float* y, int B, int T, int D, void* stream) {
+    SCAT_REQUIRE(x && y && B > 0 && T > 0 && D > 0, SCAT_E_ARG, "scat_token_mean_fwd: bad argument");
+    int64_t n = (int64_t)B * D;
+    hipLaunchKernelGGL(tokmean_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, T, D);
+    SCAT_LAUNCH_CHECK("scat_token_mean_fwd");
+    return SCAT_OK;
+}
+extern "C" int scat_token_mean_bwd(const float* dy, float* dx, int B, int T, int D, void* stream) {
+    SCAT_REQUIRE(dy && dx && B > 0 && T > 0 && D > 0, SCAT_E_ARG, "scat_token_mean_bwd: bad argument");
+    int64_t n = (int64_t)B * T * D;
+    hipLaunchKernelGGL(tokmean_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, T, D);
+    SCAT_LAUNCH_CHECK("scat_token_mean_bwd");
+    return SCAT_OK;
+}
+
 extern "C" int scat_tokens_fwd(const float* x, const float* pe, const float* mask_token, const int32_t* masked,
                                int nmasked, float* y, int B, int T, int D, void* stream) {
     SCAT_REQUIRE(x && y && B > 0 && T > 0 && D > 0, SCAT_E_ARG, "scat_tokens_fwd: bad argument");
@@ -366,11 +446,12 @@ extern "C" int scat_tokens_bwd(const float* dy, const int32_t* masked, int nmask
 
 extern "C" int scat_regressor_fwd(const float* feat, const float* feat_out, const float* mean, const float* w,
                                   const float* bias, float* preds, float* out, int B, int F, int P, int iters,
-                                  void* stream) {
-    SCAT_REQUIRE(feat && feat_out && mean && w && bias && preds && out, SCAT_E_ARG, "scat_regressor_fwd: null pointer");
-    SCAT_REQUIRE(B > 0 && F > 0 && P == 66 && iters >= 0, SCAT_E_SHAPE, "scat_regressor_fwd: need P == 66");
+                                  int root_relative, void* stream) {
+    SCAT_REQUIRE(feat && mean && w && bias && preds && out, SCAT_E_ARG, "scat_regressor_fwd: null pointer");
+    SCAT_REQUIRE(B > 0 && F > 0 && P >= 9 && P <= 128 && iters >= 0, SCAT_E_SHAPE, "scat_regressor_fwd: need 9 <= P <= 128");
+    SCAT_REQUIRE(!root_relative || (P - 3) % 3 == 0, SCAT_E_SHAPE, "scat_regressor_fwd: root-relative needs P = 3 + 3J");
     hipLaunchKernelGGL(regressor_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, feat, feat_out, mean, w, bias,
-                       preds, out, B, F, P, iters);
+                       preds, out, B, F, P, iters, root_relative);
     SCAT_LAUNCH_CHECK("scat_regressor_fwd");
     return SCAT_OK;
 }
@@ -381,17 +462,16 @@ extern "C" int64_t scat_regressor_bwd_ws(int B, int F, int P, int iters) {
 
 extern "C" int scat_regressor_bwd(const float* dout, const float* feat, const float* preds, const float* w,
                                   float* dfeat, float* dfeat_out, float* dw, float* dbias, int B, int F, int P,
-                                  int iters, void* ws, int64_t ws_bytes, void* stream) {
-    SCAT_REQUIRE(dout && feat && preds && w && dfeat && dfeat_out && dw && dbias, SCAT_E_ARG,
-                 "scat_regressor_bwd: null pointer");
-    SCAT_REQUIRE(B > 0 && F > 0 && P == 66 && iters >= 0, SCAT_E_SHAPE, "scat_regressor_bwd: need P == 66");
+                                  int iters, int root_relative, void* ws, int64_t ws_bytes, void* stream) {
+    SCAT_REQUIRE(dout && feat && preds && w && dfeat && dw && dbias, SCAT_E_ARG, "scat_regressor_bwd: null pointer");
+    SCAT_REQUIRE(B > 0 && F > 0 && P >= 9 && P <= 128 && iters >= 0, SCAT_E_SHAPE, "scat_regressor_bwd: need 9 <= P <= 128");
     SCAT_REQUIRE(ws && ws_bytes >= scat_regressor_bwd_ws(B, F, P, iters), SCAT_E_WORKSPACE,
                  "scat_regressor_bwd: workspace too small");
     float* deltas = (float*)ws;
     float* dsum = deltas + (int64_t)(iters > 0 ? iters : 1) * B * P;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(regressor_bwd_delta_kernel, dim3(B), dim3(128), 0, st, dout, w, deltas, dsum, dfeat_out, B, F,
-                       P, iters);
+                       P, iters, root_relative);
     int64_t nw = (int64_t)P * (F + P);
     hipLaunchKernelGGL(regressor_bwd_w_kernel, dim3((int)((nw + 255) / 256)), dim3(256), 0, st, feat, preds,
                        (const float*)deltas, (const float*)dsum, dw, dbias, B, F, P, iters);

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from .. import nn as snn
 from .. import ops
-from . import resnet, vision_transformer
+from . import hrnet, resnet, vision_transformer, vit
 
 
 def get_model(arch):
@@ -82,6 +82,65 @@ class _RegressorFn(torch.autograd.Function):
         feat, preds, w = ctx.saved_tensors
         dfeat, dfo, dw, db = ops.regressor_bwd(dout.contiguous(), feat, preds, w, ctx.iters)
         return dfeat, dfo, None, dw, db, None
+
+
+class _HeadLoopFn(torch.autograd.Function):
+    """``iteration`` x (pred += Linear([feat, pred])) from a constant start vector — the head of the HRNet
+    wrapper (models/hand_net.py:206-211) and of ViP (models/vision_performer.py:112-115)."""
+
+    @staticmethod
+    def forward(ctx, feat, mean, w, b, iters):
+        feat, w = feat.contiguous(), w.contiguous()
+        out, preds = ops.regressor_fwd(feat, None, mean, w, b, iters, root_relative=False)
+        ctx.save_for_backward(feat, preds, w)
+        ctx.iters = iters
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, preds, w = ctx.saved_tensors
+        dfeat, _, dw, db = ops.regressor_bwd(dout.contiguous(), feat, preds, w, ctx.iters, root_relative=False,
+                                             want_dfeat_out=False)
+        return dfeat, None, dw, db, None
+
+
+class EncoderTransformerHRNet(nn.Module):
+    """models/hand_net.py:150-213.  As shipped the reference pairs this wrapper with the dim-HALVING
+    ``vision_transformer.Transformer`` and a regressor sized for a dim-preserving one, which cannot run
+    (``2x64 and 257x61``); the working wiring — and the one BASELINE config 4 names — is the
+    dim-preserving ``models.vit.Transformer`` (scale dim**-0.5, no LayerNorm), used here.  ``opt.hrnet_width``
+    (default 24 like the reference; 32 = HRNet-W32) selects the branch width."""
+
+    def __init__(self, opt, mean_params):
+        super().__init__()
+        self.mean_params = mean_params.clone().cuda()
+        self.total_params_dim = 61
+        self.main_encoder = hrnet.HRNet(c=getattr(opt, "hrnet_width", 24), nof_joints=128, bn_momentum=0.1)
+        self.conv1x1_channel_reduction = snn.Conv2d(512, 128, 3, 2, 1, bias=False)
+        self.transformer = vit.Transformer(196, opt.vit_depth, opt.vit_heads, 64, 392, 0.0)
+        self.iteration = opt.iteration
+        self.regressor = nn.Sequential(snn.Linear(196 + self.total_params_dim, self.total_params_dim))
+        self.pos_embed = opt.pos_embed
+        self.positionalEncoding = PositionalEncoding(196, max_len=128)
+        self.mask_token = nn.Parameter(torch.randn(1, 1, 196))
+        self.mask_rate = opt.mask_rate
+        self._midx_cache = {}
+
+    def forward(self, main_input):
+        main_feat = self.main_encoder(main_input)                               # [B,128,56,56]
+        B = main_feat.size(0)
+        feat = self.conv1x1_channel_reduction(main_feat.view(B, 512, 28, 28))   # legal only at 224x224
+        midx = None
+        if 0.1 <= self.mask_rate <= 0.9:
+            masked = list(range(128))
+            random.shuffle(masked)
+            masked = masked[: int(self.mask_rate * 128)]
+            midx = torch.tensor(masked, dtype=torch.int32, device=feat.device) if masked else None
+        pe = self.positionalEncoding.pe[0] if self.pos_embed else None
+        tokens = _TokensFn.apply(feat.view(B, 128, -1), pe, self.mask_token, midx)
+        feat = snn.token_mean(self.transformer(tokens, None))                   # [B,196]
+        lin = self.regressor[0]
+        return _HeadLoopFn.apply(feat, self.mean_params.reshape(-1), lin.weight, lin.bias, self.iteration)
 
 
 class EncoderTransformer(nn.Module):

@@ -200,3 +200,57 @@ class Dropout(nn.Module):
         if self.p > 0 and self.training:
             raise NotImplementedError("scat_amd: dropout p>0 in training is not implemented on the HIP path")
         return x
+
+
+class _UpsampleFn(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2**k, mode='nearest') (models/hrnet.py:107)."""
+
+    @staticmethod
+    def forward(ctx, x, factor):
+        ctx.factor = factor
+        return ops.upsample_nearest_fwd(_c(x), factor)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample_nearest_bwd(_c(dy), ctx.factor), None
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.axpy(_c(a), _c(b), 1.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class _TokenMeanFn(torch.autograd.Function):
+    """x.mean(dim=1) over tokens (models/hand_net.py:203; models/vision_performer.py:108)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.T = x.shape[1]
+        return ops.token_mean_fwd(_c(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.token_mean_bwd(_c(dy), ctx.T)
+
+
+def add(a, b):
+    return _AddFn.apply(a, b)
+
+
+def token_mean(x):
+    return _TokenMeanFn.apply(x)
+
+
+class Upsample(nn.Module):
+    def __init__(self, scale_factor, mode="nearest"):
+        super().__init__()
+        assert mode == "nearest" and float(scale_factor) == int(scale_factor)
+        self.scale_factor, self.mode = float(scale_factor), mode
+
+    def forward(self, x):
+        return _UpsampleFn.apply(x, int(self.scale_factor))

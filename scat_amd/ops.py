@@ -344,28 +344,60 @@ def tokens_bwd(dy, masked_idx, want_dmask=True):
     return dx, dm
 
 
-def regressor_fwd(feat, feat_out, mean, w, bias, iters):
+def upsample_nearest_fwd(x, factor):
+    _chk(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, H * factor, W * factor), dtype=torch.float32, device=x.device)
+    lib().scat_upsample_nearest_fwd(_p(x), _p(y), B, C, H, W, factor, _stream())
+    return y
+
+
+def upsample_nearest_bwd(dy, factor):
+    _chk(dy)
+    B, C, OH, OW = dy.shape
+    dx = torch.empty((B, C, OH // factor, OW // factor), dtype=torch.float32, device=dy.device)
+    lib().scat_upsample_nearest_bwd(_p(dy), _p(dx), B, C, OH // factor, OW // factor, factor, _stream())
+    return dx
+
+
+def token_mean_fwd(x):
+    _chk(x)
+    B, T, D = x.shape
+    y = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    lib().scat_token_mean_fwd(_p(x), _p(y), B, T, D, _stream())
+    return y
+
+
+def token_mean_bwd(dy, T):
+    _chk(dy)
+    B, D = dy.shape
+    dx = torch.empty((B, T, D), dtype=torch.float32, device=dy.device)
+    lib().scat_token_mean_bwd(_p(dy), _p(dx), B, T, D, _stream())
+    return dx
+
+
+def regressor_fwd(feat, feat_out, mean, w, bias, iters, root_relative=True):
     _chk(feat, feat_out, mean, w, bias)
     B, F = feat.shape
     P = w.shape[0]
     preds = torch.empty((iters + 1, B, P), dtype=torch.float32, device=feat.device)
     out = torch.empty((B, P), dtype=torch.float32, device=feat.device)
     lib().scat_regressor_fwd(_p(feat), _p(feat_out), _p(mean), _p(w), _p(bias), _p(preds), _p(out), B, F, P, iters,
-                             _stream())
+                             int(root_relative), _stream())
     return out, preds
 
 
-def regressor_bwd(dout, feat, preds, w, iters):
+def regressor_bwd(dout, feat, preds, w, iters, root_relative=True, want_dfeat_out=True):
     _chk(dout, feat, preds, w)
     B, F = feat.shape
     P = w.shape[0]
     dfeat = torch.empty_like(feat)
-    dfeat_out = torch.empty((B, P - 3), dtype=torch.float32, device=feat.device)
+    dfeat_out = torch.empty((B, P - 3), dtype=torch.float32, device=feat.device) if want_dfeat_out else None
     dw = torch.empty_like(w)
     dbias = torch.empty((P,), dtype=torch.float32, device=feat.device)
     ws = workspace(lib().scat_regressor_bwd_ws(B, F, P, iters), feat.device)
     lib().scat_regressor_bwd(_p(dout), _p(feat), _p(preds), _p(w), _p(dfeat), _p(dfeat_out), _p(dw), _p(dbias), B, F,
-                             P, iters, _p(ws), ws.numel(), _stream())
+                             P, iters, int(root_relative), _p(ws), ws.numel(), _stream())
     return dfeat, dfeat_out, dw, dbias
 
 

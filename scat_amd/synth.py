@@ -222,3 +222,42 @@ def to_torch(sd, device="cpu"):
     import torch
 
     return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v)).to(device)) for k, v in sd.items())
+
+
+def fill_state(seed: int, template) -> "OrderedDict[str, np.ndarray]":
+    """Deterministic values for ANY module's state_dict, keyed by entry name and shape (template: name ->
+    tensor/array/shape).  Conv/Linear weights get fan-in scaling, BN/LN affine and running stats get
+    non-trivial values; used where the key list is long (HRNet: 1.7k entries) and comes from the module."""
+    sd = OrderedDict()
+    for k, t in template.items():
+        shape = tuple(t) if isinstance(t, (tuple, list)) else tuple(t.shape)
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            sd[k] = np.array(0, dtype=np.int64)
+        elif leaf == "running_mean":
+            sd[k] = uniform(seed, k, shape, -0.2, 0.2)
+        elif leaf == "running_var":
+            sd[k] = uniform(seed, k, shape, 0.6, 1.4)
+        elif leaf == "pe":
+            sd[k] = positional_encoding(shape[-1], shape[-2])
+        elif len(shape) == 1 and leaf == "weight":       # BN / LN scale
+            sd[k] = uniform(seed, k, shape, 0.5, 1.5)
+        elif len(shape) == 1:                            # biases
+            sd[k] = uniform(seed, k, shape, -0.2, 0.2)
+        elif len(shape) == 4:                            # conv weight
+            sd[k] = normal_like(seed, k, shape, std=np.sqrt(2.0 / (shape[1] * shape[2] * shape[3])))
+        elif len(shape) == 2:                            # linear weight
+            sd[k] = normal_like(seed, k, shape, std=np.sqrt(1.0 / shape[1]))
+        else:                                            # tokens and the like
+            sd[k] = normal_like(seed, k, shape, std=1.0)
+    return sd
+
+
+def hrnet_wrapper_state(seed: int, template) -> "OrderedDict[str, np.ndarray]":
+    """fill_state for EncoderTransformerHRNet, with the token-producing conv scaled so tokens are O(1):
+    the wrapper's transformer (models/vit.py) has no LayerNorm and softmax scale dim**-0.5, so with
+    O(60) tokens its output moves 0.5 % under a 1e-6 input perturbation (measured) and no fp32
+    implementation can be compared against another."""
+    sd = fill_state(seed, template)
+    sd["conv1x1_channel_reduction.weight"] = (sd["conv1x1_channel_reduction.weight"] * 0.02).astype(np.float32)
+    return sd

@@ -242,3 +242,47 @@ def test_against_oracle_config1():
     assert e_hip.max() <= 3 * e_cpu.max() + 1e-4, (e_hip.max(), e_cpu.max())
     assert np.mean(e_hip) <= 2 * np.mean(e_cpu) + 1e-4, (np.mean(e_hip), np.mean(e_cpu))
     assert named["mask_token"].grad is None or float(named["mask_token"].grad.abs().max()) == 0.0
+
+
+def test_hrnet_golden(golden):
+    """BASELINE config 4 backbone: HRNet-W32 on the HIP kernels vs the reference modules (train fwd+bwd, eval)."""
+    from scat_amd.models import hrnet as H
+
+    g = golden("hrnet")
+    net = H.HRNet(c=32, nof_joints=128, bn_momentum=0.1)
+    net.load_state_dict(synth.to_torch(synth.fill_state(101, net.state_dict())), strict=True)
+    net.cuda().train()
+    x = T(synth.images(102, 1)).cuda()
+    y = net(x)
+    assert tuple(y.shape) == (1, 128, 56, 56)
+    assert digest_err(digest(y, 64), g["y"]) < 1e-4
+    assert rel_err(y[0, :4, :4, :8], g["y_head"]) < 1e-4
+    assert rel_err(y.double().sum(dim=(0, 2, 3)), g["y_chsum"]) < 1e-4
+    (y * T(synth.normal_like(103, "cot", tuple(y.shape))).cuda()).sum().backward()
+    named = dict(net.named_parameters())
+    for k in ("final_layer.weight", "final_layer.bias"):
+        assert digest_err(digest(named[k].grad, 8), g["g:" + k]) < 1e-3, k      # at the output: tight
+    for k in ("stage4.2.fuse_layers.0.3.1.weight", "conv1.weight", "stage3.1.fuse_layers.0.2.0.weight", "stage2.0.branches.1.2.conv1.weight",
+              "transition2.2.0.0.weight", "layer1.0.downsample.0.weight"):
+        assert digest_err(digest(named[k].grad, 8), g["g:" + k]) < 0.25, k      # B=1 train-mode BN: fp32 noise level
+    assert rel_err(net.stage4[2].branches[0][3].bn2.running_mean, g["stage4.2.bn.rm"]) < 1e-4
+    net.eval()
+    with torch.no_grad():
+        assert digest_err(digest(net(x), 64), g["y_eval"]) < 1e-4
+
+
+def test_hrnet_wrapper_golden(golden):
+    from scat_amd.models.hand_net import EncoderTransformerHRNet
+
+    g = golden("hrnet")
+    net = EncoderTransformerHRNet(opt_ns(), T(synth.mean_params(104, 61)))
+    net.load_state_dict(synth.to_torch(synth.hrnet_wrapper_state(105, net.state_dict())), strict=True)
+    net.cuda().train()
+    random.seed(7)
+    p = net(T(synth.images(106, 2)).cuda())
+    assert rel_err(p, g["wrap:pred"]) < 1e-4
+    p.square().sum().backward()
+    assert digest_err(digest(net.regressor[0].weight.grad, 8), g["wrap:g:regressor.0.weight"]) < 1e-3
+    assert digest_err(digest(net.mask_token.grad, 8), g["wrap:g:mask_token"]) < 5e-3
+    assert digest_err(digest(net.transformer.layers[0][0].fn.to_qkv.weight.grad, 8),
+                      g["wrap:g:transformer.layers.0.0.fn.to_qkv.weight"]) < 5e-3

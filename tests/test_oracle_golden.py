@@ -161,3 +161,44 @@ def test_performer(golden):
     for k, p in sd.items():
         if p.grad is not None:
             assert digest_err(digest(p.grad, 8), g["g:" + k]) < 2e-5, k
+
+
+def test_hrnet(golden):
+    """HRNet(c=32,128) + the HRNet wrapper: oracle vs the reference modules' outputs."""
+    from scat_amd.models import hrnet as H
+
+    g = golden("hrnet")
+    tmpl = {k: tuple(v.shape) for k, v in H.HRNet(c=32, nof_joints=128).state_dict().items()}
+    sd = synth.to_torch(synth.fill_state(101, tmpl))
+    for k, p in sd.items():
+        if p.dtype == torch.float32 and "running" not in k:
+            p.requires_grad_(True)
+    x = T(synth.images(102, 1))
+    y = O.hrnet_forward(sd, x, "", True)
+    assert digest_err(digest(y, 64), g["y"]) < 5e-6
+    assert rel_err(y[0, :4, :4, :8], g["y_head"]) < 5e-6
+    (y * T(synth.normal_like(103, "cot", tuple(y.shape)))).sum().backward()
+    for k in ("conv1.weight", "final_layer.weight", "final_layer.bias", "stage3.1.fuse_layers.0.2.0.weight",
+              "transition2.2.0.0.weight"):
+        assert digest_err(digest(sd[k].grad, 8), g["g:" + k]) < 1e-3, k
+    assert rel_err(sd["stage4.2.branches.0.3.bn2.running_mean"], g["stage4.2.bn.rm"]) < 5e-6
+    with torch.no_grad():
+        assert digest_err(digest(O.hrnet_forward(sd, x, "", False), 64), g["y_eval"]) < 5e-6
+
+
+def test_hrnet_wrapper(golden):
+    from types import SimpleNamespace
+
+    from scat_amd.models.hand_net import EncoderTransformerHRNet
+
+    g = golden("hrnet")
+    torch.Tensor.cuda, keep = (lambda self, *a, **k: self), torch.Tensor.cuda
+    try:
+        net = EncoderTransformerHRNet(SimpleNamespace(vit_heads=8, vit_depth=3, iteration=3, pos_embed=True,
+                                                      mask_rate=0.2), T(synth.mean_params(104, 61)))
+    finally:
+        torch.Tensor.cuda = keep
+    sd = synth.to_torch(synth.hrnet_wrapper_state(105, {k: tuple(v.shape) for k, v in net.state_dict().items()}))
+    random.seed(7)
+    p = O.encoder_transformer_hrnet_forward(sd, T(synth.mean_params(104, 61)), T(synth.images(106, 2)))
+    assert rel_err(p, g["wrap:pred"]) < 5e-6
