@@ -113,12 +113,25 @@ int scat_attention_fwd(const float* qkv, float* out, float* attn, int B, int n, 
 int scat_attention_bwd(const float* dout, const float* qkv, const float* attn, float* dqkv, int B, int n, int heads,
                        int dim_head, float scale, void* stream);
 
+/* ---- performer (FAVOR+) linear attention core: models/vision_performer.py:34-53 ----
+ * kqv[B,T,heads,3e] (k|q|v per head, one shared Linear, :17,47), w[m,e] frozen random features (:32);
+ * y[B,T,heads*e].  Saved for backward: kp,qp[B,heads,T,m], kptv[B,heads,e,m], ksum[B,heads,m], D[B,heads,T]. */
+int scat_performer_fwd(const float* kqv, const float* w, float* y, float* kp, float* qp, float* kptv, float* ksum,
+                       float* D, int B, int T, int heads, int e, int m, void* stream);
+int64_t scat_performer_bwd_ws(int B, int T, int heads, int e, int m);
+int scat_performer_bwd(const float* dy, const float* kqv, const float* w, const float* y, const float* kp,
+                       const float* qp, const float* kptv, const float* ksum, const float* D, float* dkqv, int B, int T,
+                       int heads, int e, int m, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- elementwise ---- */
 /* exact-erf GELU (nn.GELU default), models/vision_transformer.py:34 */
 int scat_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int scat_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 int scat_relu_fwd(const float* x, float* y, int64_t n, void* stream);
 int scat_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+/* inverted dropout, mask = counter hash of (seed, index): the same call with dy regenerates the mask for the
+ * backward (vision_performer.py:18,28 Dropout(0.1), active in train mode) */
+int scat_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 /* y = a + alpha*b */
 int scat_axpy(const float* a, const float* b, float alpha, float* y, int64_t n, void* stream);
 /* column sums: out[j] (+)= sum_i x[i*cols + j]  (bias gradients), fixed order */

@@ -235,6 +235,20 @@ def g_performer():
     for k, p in blk.named_parameters():
         if p.grad is not None:
             out["g:" + k] = digest(p.grad, 8)
+    # ViP(heads=16, emb_s=49, iteration=5) on 64x64 images, eval mode (dropout off)
+    vip = P.ViP(opt_ns(iteration=5), T(synth.mean_params(94, 10)), heads=16, emb_s=49)
+    load_strict(vip, synth.to_torch(synth.vip_state(95, vip.state_dict())))
+    vip.eval()
+    xi = T(synth.images(96, 2, 64))
+    pv = vip(xi)
+    pv.square().sum().backward()
+    assert all(torch.isfinite(q.grad).all() for q in vip.parameters() if q.grad is not None), "NaN in reference"
+    out["vip:pred"] = pv.detach().numpy()
+    out["vip:g:head.weight"] = digest(vip.head.weight.grad, 8)
+    out["vip:g:patch_emb.weight"] = digest(vip.patch_emb.weight.grad, 8)
+    out["vip:g:mains.0.kqv.weight"] = digest(vip.mains[0].kqv.weight.grad, 8)
+    out["vip:g:cls_token"] = digest(vip.cls_token.grad, 8)
+    out["vip:g:pos_emb"] = digest(vip.pos_emb.grad, 8)
     np.savez(os.path.join(GOLD, "performer.npz"), **out)
 
 

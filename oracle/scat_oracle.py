@@ -246,6 +246,21 @@ def performer_block(sd, x, prefix, emb_s, head):
     return x + F.linear(h, sd[prefix + "mlp.2.weight"], sd[prefix + "mlp.2.bias"])
 
 
+def vip_forward(sd, mean_params, x, heads, emb_s, depth=3, iteration=3, patch=4):
+    """ViP.forward in eval mode, models/vision_performer.py:102-116."""
+    b = x.shape[0]
+    t = F.unfold(x, kernel_size=patch, stride=patch).transpose(1, 2)                       # :104
+    t = F.linear(t, sd["patch_emb.weight"], sd["patch_emb.bias"]) + sd["pos_emb"]
+    t = torch.cat([sd["cls_token"].repeat(b, 1, 1), t], dim=1)
+    for l in range(depth):
+        t = performer_block(sd, t, f"mains.{l}.", emb_s, heads)
+    feat = t.mean(dim=1)
+    pred = mean_params.repeat(b, 1)
+    for _ in range(iteration):
+        pred = pred + F.linear(torch.cat([feat, pred], dim=1), sd["head.weight"], sd["head.bias"])
+    return pred
+
+
 # --------------------------------------------------------------------------
 # model — models/hand_net.py:315-398
 # --------------------------------------------------------------------------

@@ -14,6 +14,7 @@ LIBPATH = os.path.join(HERE, "libscat_hip.so")
 _CT = {
     "int": ctypes.c_int,
     "int64_t": ctypes.c_int64,
+    "uint64_t": ctypes.c_uint64,
     "float": ctypes.c_float,
 }
 

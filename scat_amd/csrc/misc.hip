@@ -64,6 +64,17 @@ __global__ void axpy_kernel(const float* __restrict__ a, const float* __restrict
     GRID_STRIDE(e, n) y[e] = a[e] + alpha * b[e];
 }
 
+// inverted dropout with a counter-hash mask (regenerated in backward from the same seed): y = x*keep/(1-p)
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p, float scale,
+                               uint64_t seed) {
+    GRID_STRIDE(e, n) {
+        uint64_t z = (uint64_t)e * 0xD1342543DE82EF95ull + seed;
+        z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+        float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+        y[e] = u >= p ? x[e] * scale : 0.f;
+    }
+}
+
 __global__ void tokens_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pe,
                                   const float* __restrict__ mask_token, const int32_t* __restrict__ masked,
                                   int nmasked, float* __restrict__ y, int64_t total, int T, int D) {
@@ -417,6 +428,11 @@ extern "C" int scat_token_mean_bwd(const float* dy, float* dx, int B, int T, int
     hipLaunchKernelGGL(tokmean_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, T, D);
     SCAT_LAUNCH_CHECK("scat_token_mean_bwd");
     return SCAT_OK;
+}
+
+extern "C" int scat_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+    SCAT_REQUIRE(x && y && p >= 0.f && p < 1.f, SCAT_E_ARG, "scat_dropout: bad argument");
+    EW_ENTRY(scat_dropout, dropout_kernel, x, y, n, p, 1.0f / (1.0f - p), seed)
 }
 
 extern "C" int scat_tokens_fwd(const float* x, const float* pe, const float* mask_token, const int32_t* masked,

@@ -189,8 +189,21 @@ class BatchNorm2d(nn.BatchNorm2d):
                                   self.momentum, self.eps, self.fuse_relu)
 
 
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return ops.dropout(_c(x), p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(_c(dy), ctx.p, ctx.seed), None, None
+
+
 class Dropout(nn.Module):
-    """p = 0 everywhere on the reference's reg_transformer path (hand_net.py:331 dropout=0.0)."""
+    """nn.Dropout.  p = 0 on the reg_transformer path (hand_net.py:331); the performer block uses p = 0.1 in train
+    mode (vision_performer.py:18,28).  The mask comes from a counter hash seeded from python ``random`` — the same
+    distribution as torch's, not the same bits (torch's Philox stream is not reproducible off-device either)."""
 
     def __init__(self, p=0.0):
         super().__init__()
@@ -198,7 +211,9 @@ class Dropout(nn.Module):
 
     def forward(self, x):
         if self.p > 0 and self.training:
-            raise NotImplementedError("scat_amd: dropout p>0 in training is not implemented on the HIP path")
+            import random
+
+            return _DropoutFn.apply(x, self.p, random.getrandbits(63))
         return x
 
 

@@ -289,6 +289,41 @@ def attention_bwd(dout, qkv, attn, heads, dim_head, scale):
     return dqkv
 
 
+def performer_fwd(kqv, w, heads):
+    """kqv[B,T,heads,3e], w[m,e] -> (y[B,T,heads*e], saved tuple)"""
+    _chk(kqv, w)
+    B, T, H, e3 = kqv.shape
+    e, m = e3 // 3, w.shape[0]
+    dev = kqv.device
+    y = torch.empty((B, T, H * e), dtype=torch.float32, device=dev)
+    kp = torch.empty((B, H, T, m), dtype=torch.float32, device=dev)
+    qp = torch.empty_like(kp)
+    kptv = torch.empty((B, H, e, m), dtype=torch.float32, device=dev)
+    ksum = torch.empty((B, H, m), dtype=torch.float32, device=dev)
+    D = torch.empty((B, H, T), dtype=torch.float32, device=dev)
+    lib().scat_performer_fwd(_p(kqv), _p(w), _p(y), _p(kp), _p(qp), _p(kptv), _p(ksum), _p(D), B, T, H, e, m, _stream())
+    return y, (kp, qp, kptv, ksum, D)
+
+
+def performer_bwd(dy, kqv, w, y, saved):
+    _chk(dy, kqv, w, y)
+    B, T, H, e3 = kqv.shape
+    e, m = e3 // 3, w.shape[0]
+    kp, qp, kptv, ksum, D = saved
+    dkqv = torch.empty_like(kqv)
+    ws = workspace(lib().scat_performer_bwd_ws(B, T, H, e, m), kqv.device)
+    lib().scat_performer_bwd(_p(dy), _p(kqv), _p(w), _p(y), _p(kp), _p(qp), _p(kptv), _p(ksum), _p(D), _p(dkqv), B, T,
+                             H, e, m, _p(ws), ws.numel(), _stream())
+    return dkqv
+
+
+def dropout(x, p, seed):
+    _chk(x)
+    y = torch.empty_like(x)
+    lib().scat_dropout(_p(x), _p(y), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+    return y
+
+
 def gelu_fwd(x):
     _chk(x)
     y = torch.empty_like(x)

@@ -261,3 +261,14 @@ def hrnet_wrapper_state(seed: int, template) -> "OrderedDict[str, np.ndarray]":
     sd = fill_state(seed, template)
     sd["conv1x1_channel_reduction.weight"] = (sd["conv1x1_channel_reduction.weight"] * 0.02).astype(np.float32)
     return sd
+
+
+def vip_state(seed: int, template) -> "OrderedDict[str, np.ndarray]":
+    """fill_state for ViP with Linear weights scaled to the reference's own init regime (std 0.02-ish,
+    vision_performer.py:93-100): FAVOR+ has no stabiliser in exp(w.x - |x|^2/2) and no eps on its
+    denominator, so O(1) projections overflow to NaN gradients in the reference itself."""
+    sd = fill_state(seed, template)
+    for k, v in sd.items():
+        if v.ndim == 2 and k.endswith("weight"):
+            sd[k] = (v * 0.25).astype(np.float32)
+    return sd

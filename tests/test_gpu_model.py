@@ -286,3 +286,43 @@ def test_hrnet_wrapper_golden(golden):
     assert digest_err(digest(net.mask_token.grad, 8), g["wrap:g:mask_token"]) < 5e-3
     assert digest_err(digest(net.transformer.layers[0][0].fn.to_qkv.weight.grad, 8),
                       g["wrap:g:transformer.layers.0.0.fn.to_qkv.weight"]) < 5e-3
+
+
+def test_performer_block_golden(golden):
+    """BASELINE config 5 block: performer_attn_block(49, 16) eval-mode fwd/bwd vs the reference module."""
+    from scat_amd.models import vision_performer as P
+
+    g = golden("performer")
+    blk = P.performer_attn_block(49, 16)
+    blk.load_state_dict(synth.to_torch(synth.performer_state(91, "")), strict=True)
+    blk.cuda().eval()
+    x = T(synth.normal_like(92, "x", (2, 21, 784), std=0.5)).cuda().requires_grad_(True)
+    y = blk(x)
+    assert digest_err(digest(y, 64), g["y"]) < 2e-5
+    assert rel_err(y[0, :4, :16], g["y_head"]) < 2e-5
+    (y * T(synth.normal_like(93, "cot", (2, 21, 784))).cuda()).sum().backward()
+    assert digest_err(digest(x.grad, 64), g["dx"]) < 5e-5
+    assert blk.w.grad is None
+    for k, p in blk.named_parameters():
+        if p.requires_grad:
+            assert digest_err(digest(p.grad, 8), g["g:" + k]) < 1e-4, k
+
+
+def test_vip_golden(golden):
+    from scat_amd.models.vision_performer import ViP
+
+    g = golden("performer")
+    net = ViP(opt_ns(iteration=5), T(synth.mean_params(94, 10)), heads=16, emb_s=49)
+    net.load_state_dict(synth.to_torch(synth.vip_state(95, net.state_dict())), strict=True)
+    net.cuda().eval()
+    p = net(T(synth.images(96, 2, 64)).cuda())
+    assert rel_err(p, g["vip:pred"]) < 1e-4
+    p.square().sum().backward()
+    named = dict(net.named_parameters())
+    for k in ("head.weight", "patch_emb.weight", "mains.0.kqv.weight", "cls_token", "pos_emb"):
+        assert digest_err(digest(named[k].grad, 8), g["vip:g:" + k]) < 2e-3, k
+    # train mode runs (dropout p = 0.1 with the hash mask) and keeps the expected scale
+    net.train()
+    random.seed(1)
+    pt = net(T(synth.images(96, 2, 64)).cuda())
+    assert torch.isfinite(pt).all() and rel_err(pt, g["vip:pred"]) < 0.5

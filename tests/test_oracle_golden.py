@@ -202,3 +202,19 @@ def test_hrnet_wrapper(golden):
     random.seed(7)
     p = O.encoder_transformer_hrnet_forward(sd, T(synth.mean_params(104, 61)), T(synth.images(106, 2)))
     assert rel_err(p, g["wrap:pred"]) < 5e-6
+
+
+def test_vip(golden):
+    from types import SimpleNamespace
+
+    from scat_amd.models.vision_performer import ViP
+
+    g = golden("performer")
+    torch.Tensor.cuda, keep = (lambda self, *a, **k: self), torch.Tensor.cuda
+    try:
+        net = ViP(SimpleNamespace(iteration=5), T(synth.mean_params(94, 10)), heads=16, emb_s=49)
+    finally:
+        torch.Tensor.cuda = keep
+    sd = synth.to_torch(synth.vip_state(95, {k: tuple(v.shape) for k, v in net.state_dict().items()}))
+    p = O.vip_forward(sd, T(synth.mean_params(94, 10)), T(synth.images(96, 2, 64)), 16, 49, 3, 5)
+    assert rel_err(p, g["vip:pred"]) < 5e-6
