@@ -376,27 +376,20 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
 }
 
-// PF = k-pairs whose LDS fragments are fetched ahead as one register chunk (0: fetch per k-pair).
-// ABL (timing experiments only, results invalid): 1 no global loads, 2 +no LDS stores, 3 +no barrier, 4 +no ds_reads.
-template <class LA, class LB, int BM, int BN, int BK, int WM, int WN, int PF = 0, int SCHED = 0, int ABL = 0>
+// PD = prefetch distance in K-steps.  PD = 1: the loads of step t+1 fly under the MFMAs of step t.
+// PD = 2: a second register set keeps the loads of step t+2 in flight as well (twice the bytes in flight per
+// CU — what the HBM-bound short-K layers need, MI355X wants >= 64 KiB in flight per CU to hide an HBM miss).
+template <class LA, class LB, int BM, int BN, int BK, int WM, int WN, int PD = 1>
 __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename LB::Desc db, OutDesc dc,
-                                                  int M, int N, int K, int kchunk, int stagger) {
+                                                  int M, int N, int K, int kchunk) {
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     static_assert(WM * WN == 4 && MI >= 1 && NI >= 1, "wave layout");
+    static_assert(PD == 1 || PD == 2, "prefetch distance");
     constexpr int SA = BM + LPAD, SB = BN + LPAD;
     extern __shared__ __align__(16) float lds[];   // 2*BK*(SA+SB) floats: A buffers 0,1 then B buffers 0,1
     auto As = [&](int buf) -> float* { return lds + buf * (BK * SA); };
     auto Bs = [&](int buf) -> float* { return lds + 2 * BK * SA + buf * (BK * SB); };
 
-    // De-phase the workgroups that share a CU: identical workgroups started together stay in lockstep
-    // (all compute, then all store), so the MFMA pipes idle while HBM drains the epilogues and vice versa.
-    // The first resident generation is delayed by slot*stagger cycles; later generations inherit the skew.
-    // Placement (which blocks share a CU) is only a speed assumption, never correctness.
-    if (stagger > 0 && blockIdx.x < 1024 && blockIdx.x >= 256) {
-        const long long t0 = wall_clock64();
-        const long long wait = (long long)(blockIdx.x >> 8) * stagger;   // 100 MHz ticks
-        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
     const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, mt * nt);
     const int i0 = (tile % mt) * BM, j0 = (tile / mt) * BN;   // m fastest: neighbours share the B panel
@@ -407,10 +400,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    LA la;
-    LB lb;
-    la.init(da, i0, z);
-    lb.init(db, j0, z);
+    LA la[PD];
+    LB lb[PD];
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+        la[s].init(da, i0, z);
+        lb[s].init(db, j0, z);
+    }
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -421,83 +417,83 @@ __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nk = (kend - kbeg + BK - 1) / BK;
-    if (nk > 0) {
-        la.load(da, kbeg, kend);
-        lb.load(db, kbeg, kend);
-        la.store(da, As(0));
-        lb.store(db, Bs(0));
-    }
-    __syncthreads();
-    // one K-step on LDS buffer `cur`; NEXT: also stage the following tile (loads issued first so they are in
-    // flight under the MFMAs, written to the other LDS buffer afterwards).  No branches inside: the body is
-    // one scheduling region.
-    auto kstep = [&](int cur, int knext, auto next_tag) {
-        constexpr bool NEXT = decltype(next_tag)::value;
-        if constexpr (NEXT && ABL < 1) {
-            la.load(da, knext, kend);
-            lb.load(db, knext, kend);
-        }
+    // the MFMAs of one K-step on LDS buffer `cur`
+    auto mfmas = [&](int cur) {
         const float* as = As(cur) + wm * (BM / WM) + l31 + lh * SA;
         const float* bs = Bs(cur) + wn * (BN / WN) + l31 + lh * SB;
-        if constexpr (PF == 0) {
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                float av[MI], bv[NI];
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[MI], bv[NI];
 #pragma unroll
-                for (int a = 0; a < MI; ++a) av[a] = ABL >= 4 ? (float)(lane + a) : as[kk * SA + a * 32];
+            for (int a = 0; a < MI; ++a) av[a] = as[kk * SA + a * 32];
 #pragma unroll
-                for (int b = 0; b < NI; ++b) bv[b] = ABL >= 4 ? (float)(lane - b) : bs[kk * SB + b * 32];
+            for (int b = 0; b < NI; ++b) bv[b] = bs[kk * SB + b * 32];
 #pragma unroll
-                for (int a = 0; a < MI; ++a)
+            for (int a = 0; a < MI; ++a)
 #pragma unroll
-                    for (int b = 0; b < NI; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-            }
-        } else {
-            // register double-buffered fragments: the ds_reads of chunk c+1 are in flight while the MFMAs
-            // of chunk c issue
-            constexpr int NC = BK / 2 / PF;
-            float av[2][PF][MI], bv[2][PF][NI];
-#pragma unroll
-            for (int q = 0; q < PF; ++q) {
-#pragma unroll
-                for (int a = 0; a < MI; ++a) av[0][q][a] = as[(2 * q) * SA + a * 32];
-#pragma unroll
-                for (int b = 0; b < NI; ++b) bv[0][q][b] = bs[(2 * q) * SB + b * 32];
-            }
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                if (c + 1 < NC) {
-#pragma unroll
-                    for (int q = 0; q < PF; ++q) {
-#pragma unroll
-                        for (int a = 0; a < MI; ++a)
-                            av[(c + 1) & 1][q][a] = as[(2 * ((c + 1) * PF + q)) * SA + a * 32];
-#pragma unroll
-                        for (int b = 0; b < NI; ++b)
-                            bv[(c + 1) & 1][q][b] = bs[(2 * ((c + 1) * PF + q)) * SB + b * 32];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < PF; ++q)
-#pragma unroll
-                    for (int a = 0; a < MI; ++a)
-#pragma unroll
-                        for (int b = 0; b < NI; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][q][a], bv[c & 1][q][b],
-                                                                             acc[a][b], 0, 0, 0);
-            }
+                for (int b = 0; b < NI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
-        if constexpr (NEXT && ABL < 2) {
-            la.store(da, As(cur ^ 1));
-            lb.store(db, Bs(cur ^ 1));
-        }
-        if constexpr (SCHED == 1) __builtin_amdgcn_iglp_opt(0);
-        if constexpr (SCHED == 2) __builtin_amdgcn_iglp_opt(1);
-        if constexpr (ABL < 3) __syncthreads();
     };
-    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt & 1, kbeg + (kt + 1) * BK, std::true_type{});
-    if (nk > 0) kstep((nk - 1) & 1, 0, std::false_type{});
+    // K-step t: [issue loads of step t+PD into register set LS] -> MFMAs on LDS[t&1] -> [write step t+1 from
+    // register set SS to LDS[(t+1)&1]] -> barrier.  LOAD/STORE are compile-time so the body is branch-free.
+    auto kstep = [&](int t, auto ls_tag, auto ss_tag, auto load_tag, auto store_tag) {
+        constexpr int LS = decltype(ls_tag)::value, SS = decltype(ss_tag)::value;
+        if constexpr (decltype(load_tag)::value) {
+            la[LS].load(da, kbeg + (t + PD) * BK, kend);
+            lb[LS].load(db, kbeg + (t + PD) * BK, kend);
+            // hipcc otherwise sinks the buffer loads below the MFMAs, next to the ds_writes that consume them
+            // (seen in the ISA): the loads would then be waited for as soon as they are issued
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfmas(t & 1);
+        if constexpr (decltype(store_tag)::value) {
+            la[SS].store(da, As((t + 1) & 1));
+            lb[SS].store(db, Bs((t + 1) & 1));
+        }
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, PD - 1>;
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (nk > 0) {
+        la[0].load(da, kbeg, kend);
+        lb[0].load(db, kbeg, kend);
+        if constexpr (PD == 2) {
+            if (nk > 1) {
+                la[1].load(da, kbeg + BK, kend);
+                lb[1].load(db, kbeg + BK, kend);
+            }
+        }
+        la[0].store(da, As(0));
+        lb[0].store(db, Bs(0));
+    }
+    __syncthreads();
+    if constexpr (PD == 1) {
+        int t = 0;
+        for (; t + 1 < nk; ++t) kstep(t, I0{}, I0{}, T_{}, T_{});
+        if (nk > 0) kstep(t, I0{}, I0{}, F_{}, F_{});
+    } else {
+        // step t (even) consumes LDS[0]; its successor t+1 is in register set 1, step t+2 goes to set 0
+        int t = 0;
+        for (; t + 3 < nk; t += 2) {
+            kstep(t, I0{}, I1{}, T_{}, T_{});
+            kstep(t + 1, I1{}, I0{}, T_{}, T_{});
+        }
+        for (; t < nk; ++t) {   // tail (<= 3 steps): generic parity, loads/stores only while tiles remain
+            const bool ld = t + 2 < nk, st = t + 1 < nk;
+            if (t & 1) {
+                if (ld) kstep(t, I1{}, I0{}, T_{}, T_{});
+                else if (st) kstep(t, I1{}, I0{}, F_{}, T_{});
+                else kstep(t, I1{}, I0{}, F_{}, F_{});
+            } else {
+                if (ld) kstep(t, I0{}, I1{}, T_{}, T_{});
+                else if (st) kstep(t, I0{}, I1{}, F_{}, T_{});
+                else kstep(t, I0{}, I1{}, F_{}, F_{});
+            }
+        }
+    }
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Branch-free: 32-bit element offsets, raw buffer stores whose out-of-range lanes (tile edge) are
@@ -580,20 +576,20 @@ __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int splits,
                                      int accumulate);
 
-template <class LA, class LB, int BM, int BN, int BK, int WM, int WN, int PF = 0, int SCHED = 0, int ABL = 0>
+template <class LA, class LB, int BM, int BN, int BK, int WM, int WN, int PD = 1>
 static inline void launch_gemm(const typename LA::Desc& da, const typename LB::Desc& db, const OutDesc& dc, int M,
-                               int N, int K, int splits, hipStream_t st, int stagger = 0) {
+                               int N, int K, int splits, hipStream_t st) {
     int mt = cdiv(M, BM), nt = cdiv(N, BN);
     int kchunk = cdiv(cdiv(K, splits), BK) * BK;
     dim3 grid(mt * nt, 1, splits);
     constexpr size_t lds_bytes = sizeof(float) * 2 * BK * (BM + BN + 2 * LPAD);
-    auto kern = gemm_kernel<LA, LB, BM, BN, BK, WM, WN, PF, SCHED, ABL>;
+    auto kern = gemm_kernel<LA, LB, BM, BN, BK, WM, WN, PD>;
     if constexpr (lds_bytes > 64 * 1024) {
         static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)lds_bytes) == hipSuccess);
         (void)once;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds_bytes, st, da, db, dc, M, N, K, kchunk, stagger);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds_bytes, st, da, db, dc, M, N, K, kchunk);
 }
 
 int tuning();   // SCAT_TUNE environment knob for kernel-variant experiments (0 = shipped default)
