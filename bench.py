@@ -102,9 +102,17 @@ def dominant_kernel_roofline(ts, x, lab):
     tf = flops / (ms * 1e-3) / 1e12
     table = {k: {"launches": v[2], "ms": round(v[0], 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2)}
              for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
+    # collected separately, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); null if this kernel was not profiled
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            traffic = json.load(fh).get(name, {}).get("hbm_bytes_per_launch")
+    except OSError:
+        pass
     roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_F32_MFMA_TF, 4), "traffic": None, "kernel": name, "launches_per_step": n,
-            "avg_launch_ms": round(ms / n, 4)}
+            "frac": round(tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic, "kernel": name, "launches_per_step": n,
+            "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3)}
     return roof, table
 
 
