@@ -293,7 +293,28 @@ def g_hrnet():
     np.savez(os.path.join(GOLD, "hrnet.npz"), **out)
 
 
-ALL = {"hrnet": g_hrnet, "vt": g_vt, "bottleneck": g_bottleneck, "resnet": g_resnet, "encoder": g_encoder,
+def g_coarse():
+    """train_coarse.py network: EncoderTransformerCoarse B=2 (reference module), fwd 4-tuple + a few grads."""
+    from models.hand_net import EncoderTransformerCoarse
+
+    net = EncoderTransformerCoarse(opt_ns(), T(synth.mean_params(111)))
+    load_strict(net, synth.to_torch(synth.fill_state(112, net.state_dict())))
+    net.train()
+    random.seed(9)
+    x, lab = T(synth.images(113, 2)), T(synth.labels(114, 2))
+    pred, fv, attn, pl = net(x)
+    loss, *_ = O.scat_loss(pred, lab, pl)
+    loss.backward()
+    out = {"pred": pred.detach().numpy(), "attn": digest(attn, 64), "attn_head": attn[0, :2, :4, :8].detach().numpy(),
+           "fv": digest(fv, 64), "pl": digest(pl, 64), "loss": np.array(loss.item())}
+    for k in ("regressor.weight", "regressor.bias", "mask_token", "transformer.layers.0.1.norm.weight",
+              "transformer.layers.2.2.net.2.weight", "transformer.layers.1.0.to_qkv.weight",
+              "conv1x1_channel_reduction.weight"):
+        out["g:" + k] = digest(dict(net.named_parameters())[k].grad, 8)
+    np.savez(os.path.join(GOLD, "coarse.npz"), **out)
+
+
+ALL = {"coarse": g_coarse, "hrnet": g_hrnet, "vt": g_vt, "bottleneck": g_bottleneck, "resnet": g_resnet, "encoder": g_encoder,
        "trainstep": g_trainstep, "vit": g_vit, "performer": g_performer}
 
 if __name__ == "__main__":

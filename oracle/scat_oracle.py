@@ -207,6 +207,27 @@ def vt_forward(sd, x, prefix, depth=3, heads=8, dim_head=64):
     return x
 
 
+def vt_attn_forward(sd, x, prefix, depth=3, heads=8, dim_head=64):
+    """vision_transformer_attn.Transformer.forward, models/vision_transformer_attn.py:106-113:
+    x1, attn = Attention(x); x = LN(x1) + x; x = FF(LN x) | FF3(x); returns (x, last attn)."""
+    scale = dim_head ** -0.5
+    attn = None
+    for l in range(depth):
+        k = f"{prefix}layers.{l}"
+        dim = x.shape[-1]
+        a, attn = attention(x, sd[k + ".0.to_qkv.weight"], sd[k + ".0.to_out.0.weight"], sd[k + ".0.to_out.0.bias"],
+                            heads, scale)
+        x = F.layer_norm(a, (dim,), sd[k + ".1.norm.weight"], sd[k + ".1.norm.bias"], LN_EPS) + x
+        if l == depth - 1:
+            f, h = k + ".2.net", x
+        else:
+            f = k + ".2.fn.net"
+            h = F.layer_norm(x, (dim,), sd[k + ".2.norm.weight"], sd[k + ".2.norm.bias"], LN_EPS)
+        h = F.gelu(F.linear(h, sd[f + ".0.weight"], sd[f + ".0.bias"]))
+        x = F.linear(h, sd[f + ".2.weight"], sd[f + ".2.bias"])
+    return x, attn
+
+
 def vit_forward(sd, x, prefix, depth=3, heads=8):
     """vit.Transformer.forward, models/vit.py:71-84: x = Attn(x)+x; x = FF(x)+x;
     no LayerNorm; scale = dim**-0.5 (models/vit.py:41). Dropout p=0."""
@@ -300,6 +321,34 @@ def encoder_transformer_forward(sd, mean_params, x, heads=8, iteration=3, pos_em
         pl = torch.autograd.grad(feat_out.sum(), feat_visual, retain_graph=True)[0]  # :396
         return pred, feat_visual, pl
     return pred, feat_visual
+
+
+def encoder_transformer_coarse_forward(sd, mean_params, x, pos_embed=True, mask_rate=0.2, pl_reg=True,
+                                       training=True, masked=None):
+    """EncoderTransformerCoarse.forward, models/hand_net.py:262-311."""
+    feat1024, x1, x2, x3, x4 = resnet_forward(sd, x, "main_encoder.", training)
+    feat_visual = F.conv2d(x2, sd["conv1x1_channel_reduction.weight"])
+    b = feat_visual.size(0)
+    feat = feat_visual.reshape(b, 21, -1)
+    if pos_embed:
+        feat = feat + sd["positionalEncoding.pe"][: feat.size(0)]
+    if masked is None:
+        masked = mask_indices(mask_rate)
+    if len(masked):
+        feat = feat.clone()
+        feat[:, masked, :] = sd["mask_token"]
+    feat_out, attn = vt_attn_forward(sd, feat, "transformer.", 3, 8, 64)
+    feat_out = feat_out.reshape(b, -1)
+    pred = mean_params.repeat(b, 1).clone()
+    pred[:, 3:] = pred[:, 3:] + feat_out
+    cameras = F.linear(torch.cat((feat1024, pred[:, :3]), dim=1), sd["regressor.weight"], sd["regressor.bias"])
+    j = pred[:, 3:66].reshape(-1, 21, 3)
+    j = j - j[:, 1:2, :]
+    pred = torch.cat((cameras, j.reshape(-1, 63)), dim=1)
+    if pl_reg:
+        pl = torch.autograd.grad(feat_out.sum(), feat_visual, retain_graph=True)[0]
+        return pred, feat_visual, attn, pl
+    return pred, feat_visual, attn
 
 
 # --------------------------------------------------------------------------

@@ -28,9 +28,10 @@ class LayerCfg:
     scale: float       # softmax scale
     heads: int
     dim_head: int
+    post_ln: bool = False   # vision_transformer_attn: x = LN(Attn(x)) + x  (LayerNorm on the attention OUTPUT)
 
     def nparams(self):
-        return (2 if self.ln1 else 0) + 3 + (2 if self.ff_ln else 0) + 4
+        return (2 if self.ln1 else 0) + 3 + (2 if self.post_ln else 0) + (2 if self.ff_ln else 0) + 4
 
 
 class Tape:
@@ -59,8 +60,16 @@ def mixer_forward(x: torch.Tensor, cfgs: List[LayerCfg], params: List[torch.Tens
         inner = cfg.heads * cfg.dim_head
         qkv = ops.linear_fwd(h, wqkv)
         ao, attn = ops.attention_fwd(qkv.view(B, n, 3 * inner), cfg.heads, cfg.dim_head, cfg.scale)
-        x1 = cur.clone()
-        ops.linear_fwd(ao.view(M, inner), wout, bout, out=x1, accumulate=True)   # x + ao·Wᵀ + b in the epilogue
+        if cfg.post_ln:
+            gp, bp = p[k], p[k + 1]
+            k += 2
+            a1 = ops.linear_fwd(ao.view(M, inner), wout, bout)
+            n1, mup, rsp = ops.layernorm_fwd(a1, gp, bp)
+            x1 = ops.axpy(n1, cur, 1.0, out=n1)
+        else:
+            a1 = mup = rsp = None
+            x1 = cur.clone()
+            ops.linear_fwd(ao.view(M, inner), wout, bout, out=x1, accumulate=True)   # x + ao·Wᵀ + b in the epilogue
         if cfg.ff_ln:
             g2, b2 = p[k], p[k + 1]
             k += 2
@@ -76,14 +85,18 @@ def mixer_forward(x: torch.Tensor, cfgs: List[LayerCfg], params: List[torch.Tens
         else:
             x2 = ops.linear_fwd(a, w2, bb2)
         if keep:
-            recs.append((cur, h, mu1, rs1, qkv, attn, ao, x1, h2, mu2, rs2, u, a))
+            recs.append((cur, h, mu1, rs1, qkv, attn, ao, x1, h2, mu2, rs2, u, a, a1, mup, rsp))
         cur = x2
     y = cur.view(B, n, -1)
     tape = None
     if keep:
         tape = Tape()
         tape.cfgs, tape.params, tape.recs, tape.B, tape.n = cfgs, params, recs, B, n
+    last_attn[0] = attn
     return y, tape
+
+
+last_attn = [None]   # softmax probabilities [B,h,n,n] of the last layer of the most recent forward
 
 
 def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
@@ -94,13 +107,15 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
     grads: List[Optional[torch.Tensor]] = [None] * len(tape.params)
     pi = len(tape.params)
     for cfg, rec in zip(reversed(tape.cfgs), reversed(tape.recs)):
-        cur, h, mu1, rs1, qkv, attn, ao, x1, h2, mu2, rs2, u, a = rec
+        cur, h, mu1, rs1, qkv, attn, ao, x1, h2, mu2, rs2, u, a, a1, mup, rsp = rec
         npar = cfg.nparams()
         pi -= npar
         p = tape.params[pi:pi + npar]
         k = (2 if cfg.ln1 else 0)
         wqkv, wout = p[k], p[k + 1]
-        kf = k + 3 + (2 if cfg.ff_ln else 0)
+        kp = k + 3                               # post-LN params (if any)
+        kn = kp + (2 if cfg.post_ln else 0)      # FF pre-norm params (if any)
+        kf = kn + (2 if cfg.ff_ln else 0)
         w0, w2 = p[kf], p[kf + 2]
         inner = cfg.heads * cfg.dim_head
         # ---- MLP
@@ -114,18 +129,24 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
             grads[pi + kf + 1] = ops.colsum(du)
         dh2 = ops.linear_dgrad(du, w0)
         if cfg.ff_ln:
-            dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, p[k + 3], mu2, rs2)
+            dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, p[kn], mu2, rs2)
             if want_param_grads:
-                grads[pi + k + 3], grads[pi + k + 4] = dg2, db2
+                grads[pi + kn], grads[pi + kn + 1] = dg2, db2
         else:
             dx1 = dh2
         if cfg.ff_res:
             dx1 = ops.axpy(dx1, d, 1.0, out=dx1)
-        # ---- attention: x1 = x + ao·Woutᵀ + b
+        # ---- attention: x1 = x + ao·Woutᵀ + b   (post_ln: x1 = x + LN(ao·Woutᵀ + b))
+        if cfg.post_ln:
+            da1, dgp, dbp = ops.layernorm_bwd(dx1, a1, p[kp], mup, rsp)
+            if want_param_grads:
+                grads[pi + kp], grads[pi + kp + 1] = dgp, dbp
+        else:
+            da1 = dx1
         if want_param_grads:
-            grads[pi + k + 1] = ops.linear_wgrad(dx1, ao.view(M, inner))
-            grads[pi + k + 2] = ops.colsum(dx1)
-        dao = ops.linear_dgrad(dx1, wout)
+            grads[pi + k + 1] = ops.linear_wgrad(da1, ao.view(M, inner))
+            grads[pi + k + 2] = ops.colsum(da1)
+        dao = ops.linear_dgrad(da1, wout)
         dqkv = ops.attention_bwd(dao.view(B, n, inner), qkv.view(B, n, 3 * inner), attn, cfg.heads, cfg.dim_head,
                                  cfg.scale).view(M, 3 * inner)
         if want_param_grads:

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from .. import nn as snn
 from .. import ops
-from . import hrnet, resnet, vision_transformer, vit
+from . import hrnet, resnet, vision_transformer, vision_transformer_attn, vit
 
 
 def get_model(arch):
@@ -143,6 +143,61 @@ class EncoderTransformerHRNet(nn.Module):
         return _HeadLoopFn.apply(feat, self.mean_params.reshape(-1), lin.weight, lin.bias, self.iteration)
 
 
+class EncoderTransformerCoarse(nn.Module):
+    """models/hand_net.py:216-311 — the ``train_coarse.py`` network: same backbone and token path, the
+    attention-returning transformer, a single ``Linear(1027 -> 3)`` camera regressor instead of the iterative
+    loop, and a 3- or 4-tuple ``(pred_params, feat_visual, attn[B,8,21,21][, pl_term])``."""
+
+    def __init__(self, opt, mean_params):
+        super().__init__()
+        self.mean_params = mean_params.clone().cuda()
+        self.pl = opt.pl_reg
+        self.full_content = 21
+        self.conv1x1_channel_reduction = snn.Conv2d(512, 21, 1, 1, 0, bias=False)
+        self.transformer = vision_transformer_attn.Transformer(dim=784, depth=3, heads=8, dim_head=64, mlp_dim=392,
+                                                               dropout=0.0)
+        self.main_encoder = get_model("resnet50")
+        self.iteration = opt.iteration
+        self.pos_embed = opt.pos_embed
+        self.positionalEncoding = PositionalEncoding(784, max_len=21)
+        self.mask_token = nn.Parameter(torch.randn(1, 1, 784))
+        self.mask_rate = opt.mask_rate
+        self.regressor = snn.Linear(1024 + 3, 3)
+        self._midx_cache = {}
+
+    _draw_mask = None   # bound below (same python-random draw as EncoderTransformer)
+
+    def forward(self, main_input):
+        main_feat, x1, x2, x3, x4 = self.main_encoder(main_input)
+        feat_visual = self.conv1x1_channel_reduction(x2)
+        B = feat_visual.size(0)
+        midx = self._draw_mask(feat_visual.device)
+        pe = self.positionalEncoding.pe[0] if self.pos_embed else None
+        tokens = _TokensFn.apply(feat_visual.view(B, 21, -1), pe, self.mask_token, midx)
+        self.transformer._holder.want_tape = bool(self.pl)
+        feat_out, attn = self.transformer(tokens, None)
+        mean = self.mean_params.reshape(-1)
+        # joints: mean template + offsets, root-relative (no refinement loop on this variant: iters = 0)
+        joints = _RegressorFn.apply(main_feat, feat_out.reshape(B, -1), mean, self._dummy_w(), self._dummy_b(), 0)
+        cameras = self.regressor(torch.cat((main_feat, mean[:3].expand(B, 3)), dim=1))   # hand_net.py:296
+        pred_params = torch.cat((cameras, joints[:, 3:]), dim=1)
+        if self.pl:
+            dtok = self.transformer.input_grad(torch.ones_like(feat_out))
+            pl_term = ops.tokens_bwd(dtok.contiguous(), midx, want_dmask=False)[0].view_as(feat_visual)
+            return pred_params, feat_visual, attn, pl_term
+        return pred_params, feat_visual, attn
+
+    def _dummy_w(self):
+        if not hasattr(self, "_zw") or self._zw.device != self.mask_token.device:
+            self._zw = torch.zeros((66, 1024 + 66), device=self.mask_token.device)
+            self._zb = torch.zeros((66,), device=self.mask_token.device)
+        return self._zw
+
+    def _dummy_b(self):
+        self._dummy_w()
+        return self._zb
+
+
 class EncoderTransformer(nn.Module):
     def __init__(self, opt, mean_params):
         super().__init__()
@@ -198,3 +253,6 @@ class EncoderTransformer(nn.Module):
             pl_term = ops.tokens_bwd(dtok.contiguous(), midx, want_dmask=False)[0].view_as(feat_visual)
             return pred_params, feat_visual, pl_term
         return pred_params, feat_visual
+
+
+EncoderTransformerCoarse._draw_mask = EncoderTransformer._draw_mask

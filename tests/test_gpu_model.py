@@ -326,3 +326,31 @@ def test_vip_golden(golden):
     random.seed(1)
     pt = net(T(synth.images(96, 2, 64)).cuda())
     assert torch.isfinite(pt).all() and rel_err(pt, g["vip:pred"]) < 0.5
+
+
+def test_coarse_golden(golden):
+    """train_coarse.py's network: 4-tuple incl. the last layer's attention map."""
+    from scat_amd.models.hand_net import EncoderTransformerCoarse
+    from scat_amd.trainer import pose_length_term, scat_loss
+
+    g = golden("coarse")
+    net = EncoderTransformerCoarse(opt_ns(), T(synth.mean_params(111)))
+    net.load_state_dict(synth.to_torch(synth.fill_state(112, net.state_dict())), strict=True)
+    net.cuda().train()
+    random.seed(9)
+    x, lab = T(synth.images(113, 2)).cuda(), T(synth.labels(114, 2)).cuda()
+    pred, fv, attn, pl = net(x)
+    assert tuple(attn.shape) == (2, 8, 21, 21)
+    assert rel_err(pred, g["pred"]) < 1e-4
+    assert digest_err(digest(attn, 64), g["attn"]) < 1e-4 and rel_err(attn[0, :2, :4, :8], g["attn_head"]) < 1e-4
+    assert digest_err(digest(fv, 64), g["fv"]) < 1e-4
+    assert digest_err(digest(pl, 64), g["pl"]) < 5e-4
+    loss, _ = scat_loss(pred, lab)
+    total = loss + 10 * pose_length_term(pl)
+    assert abs(total.item() - float(g["loss"])) / abs(float(g["loss"])) < 1e-4
+    total.backward()
+    named = dict(net.named_parameters())
+    for k in ("regressor.weight", "regressor.bias", "mask_token", "transformer.layers.0.1.norm.weight",
+              "transformer.layers.2.2.net.2.weight", "transformer.layers.1.0.to_qkv.weight",
+              "conv1x1_channel_reduction.weight"):
+        assert digest_err(digest(named[k].grad, 8), g["g:" + k]) < 2e-3, k

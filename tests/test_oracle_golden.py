@@ -218,3 +218,25 @@ def test_vip(golden):
     sd = synth.to_torch(synth.vip_state(95, {k: tuple(v.shape) for k, v in net.state_dict().items()}))
     p = O.vip_forward(sd, T(synth.mean_params(94, 10)), T(synth.images(96, 2, 64)), 16, 49, 3, 5)
     assert rel_err(p, g["vip:pred"]) < 5e-6
+
+
+def test_coarse(golden):
+    g = golden("coarse")
+    from types import SimpleNamespace
+
+    from scat_amd.models.hand_net import EncoderTransformerCoarse
+
+    torch.Tensor.cuda, keep = (lambda self, *a, **k: self), torch.Tensor.cuda
+    try:
+        net = EncoderTransformerCoarse(SimpleNamespace(vit_heads=8, pl_reg=True, iteration=3, pos_embed=True,
+                                                       mask_rate=0.2), T(synth.mean_params(111)))
+    finally:
+        torch.Tensor.cuda = keep
+    sd = synth.to_torch(synth.fill_state(112, {k: tuple(v.shape) for k, v in net.state_dict().items()}))
+    for p in O.trainable(sd).values():
+        p.requires_grad_(True)
+    random.seed(9)
+    pred, fv, attn, pl = O.encoder_transformer_coarse_forward(sd, T(synth.mean_params(111)), T(synth.images(113, 2)))
+    assert rel_err(pred, g["pred"]) < 5e-6
+    assert digest_err(digest(attn, 64), g["attn"]) < 5e-6
+    assert digest_err(digest(pl, 64), g["pl"]) < 5e-5
