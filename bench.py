@@ -37,10 +37,10 @@ def build_inputs(batch, seed, device, src=256):
     """Synthetic uint8 source images -> [-1,1] -> bilinear 224x224 (dataset/load_STB.py:55 Resize(224))."""
     from scat_amd import synth
 
+    from scat_amd import ops
+
     u8 = torch.from_numpy(synth.randint_u8(seed, "bench_images", (batch, 3, src, src))).to(device)
-    x = u8.float() / 127.5 - 1.0
-    if src != 224:
-        x = torch.nn.functional.interpolate(x, size=(224, 224), mode="bilinear", align_corners=False)
+    x = ops.preprocess_u8(u8, (224, 224))      # normalise + bilinear resize in one HIP kernel
     lab = torch.from_numpy(synth.labels(seed + 1, batch)).to(device)
     return x.contiguous(), lab
 

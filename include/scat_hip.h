@@ -142,6 +142,10 @@ int scat_tokens_fwd(const float* x, const float* pe, const float* mask_token, co
 int scat_tokens_bwd(const float* dy, const int32_t* masked, int nmasked, float* dx, float* dmask_token, int B, int T,
                     int D, void* stream);
 
+/* input pipeline (dataset/load_STB.py:48-67: Resize(224), ToTensor, Normalize(.5,.5)): uint8 RGB image batch
+ * (hwc = 1: [B,SH,SW,3] as decoded; 0: [B,3,SH,SW]) -> x/127.5-1 -> bilinear (align_corners=False) -> fp32
+ * [B,3,OH,OW] in one pass */
+int scat_preprocess_u8(const uint8_t* src, float* dst, int B, int SH, int SW, int OH, int OW, int hwc, void* stream);
 /* nearest-neighbour upsample by an integer factor (models/hrnet.py:107) and mean over tokens
  * (hand_net.py:203 feat.mean(dim=1); vision_performer.py:108) */
 int scat_upsample_nearest_fwd(const float* x, float* y, int B, int C, int H, int W, int factor, void* stream);

@@ -24,28 +24,6 @@ static void conv_gemm_cfg(Cfg cfg, const MatDesc& da, const GatherDesc& db, cons
     static const char* const names[] = {"128x128", "128x64", "64x128", "64x64"};
     set_kernel_label("conv%dx%d%s_%sx16_a%d%s%s", KH, KW, D2 ? "_d2" : "", names[cfg], AV, BV4 ? "_b4" : "",
                      TF ? "_tf" : "");
-    if (tuning() == 2) {   // experiment: prefetch distance 2
-        set_kernel_label("conv%dx%d%s_%sx16_a%d%s%s_pd2", KH, KW, D2 ? "_d2" : "", names[cfg], AV, BV4 ? "_b4" : "",
-                         TF ? "_tf" : "");
-        switch (cfg) {
-            case C128x128:
-                launch_gemm<MatLoader<128, 16, true, AV>, GatherLoader<128, 16, KH, KW, D2, false, BV4, TF>, 128, 128,
-                            16, 2, 2, 2>(da, db, dc, M, N, K, 1, st);
-                break;
-            case C128x64:
-                launch_gemm<MatLoader<128, 16, true, AV>, GatherLoader<64, 16, KH, KW, D2, false, BV4, TF>, 128, 64, 16,
-                            2, 2, 2>(da, db, dc, M, N, K, 1, st);
-                break;
-            case C64x128:
-                launch_gemm<MatLoader<64, 16, true, AV>, GatherLoader<128, 16, KH, KW, D2, false, BV4, TF>, 64, 128, 16,
-                            2, 2, 2>(da, db, dc, M, N, K, 1, st);
-                break;
-            default:
-                launch_gemm<MatLoader<64, 16, true, AV>, GatherLoader<64, 16, KH, KW, D2, false, BV4, TF>, 64, 64, 16,
-                            2, 2, 2>(da, db, dc, M, N, K, 1, st);
-        }
-        return;
-    }
     switch (cfg) {
         case C128x128:
             launch_gemm<MatLoader<128, 16, true, AV>, GatherLoader<128, 16, KH, KW, D2, false, BV4, TF>, 128, 128, 16,

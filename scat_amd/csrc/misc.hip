@@ -234,6 +234,32 @@ __global__ __launch_bounds__(256) void regressor_bwd_feat_kernel(const float* __
     dfeat[e] = s;
 }
 
+// ---------------------------------------------------------------- input pipeline (dataset/load_STB.py:48-67)
+// uint8 image (HWC as decoded, or CHW) -> /127.5 - 1 -> bilinear resize (align_corners = False) -> fp32 NCHW.
+// One pass: 3 B/pixel read, 12 B/pixel written; replaces ToTensor + Normalize(.5,.5) + Resize(224) + H2D of fp32.
+__global__ void preprocess_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t total, int SH,
+                                  int SW, int OH, int OW, int hwc, float ry, float rx) {
+    GRID_STRIDE(e, total) {
+        int ox = e % OW;
+        int64_t r = e / OW;
+        int oy = r % OH;
+        r /= OH;
+        int c = r % 3;
+        int64_t b = r / 3;
+        float fy = fmaxf((oy + 0.5f) * ry - 0.5f, 0.f), fx = fmaxf((ox + 0.5f) * rx - 0.5f, 0.f);
+        int y0 = (int)fy, x0 = (int)fx;
+        int y1 = min(y0 + 1, SH - 1), x1 = min(x0 + 1, SW - 1);
+        float wy = fy - y0, wx = fx - x0;
+        auto at = [&](int y, int x) -> float {
+            int64_t i = hwc ? ((b * SH + y) * SW + x) * 3 + c : ((b * 3 + c) * SH + y) * (int64_t)SW + x;
+            return (float)src[i] * (1.0f / 127.5f) - 1.0f;
+        };
+        float top = at(y0, x0) + wx * (at(y0, x1) - at(y0, x0));
+        float bot = at(y1, x0) + wx * (at(y1, x1) - at(y1, x0));
+        dst[e] = top + wy * (bot - top);
+    }
+}
+
 // ---------------------------------------------------------------- nearest upsample (hrnet.py:107) / token mean
 
 __global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total, int H, int W,
@@ -395,6 +421,17 @@ extern "C" int scat_relu_bwd(const float* dy, const float* y, float* dx, int64_t
 extern "C" int scat_axpy(const float* a, const float* b, float alpha, float* y, int64_t n, void* stream) {
     SCAT_REQUIRE(a && b && y, SCAT_E_ARG, "scat_axpy: null pointer");
     EW_ENTRY(scat_axpy, axpy_kernel, a, b, alpha, y, n)
+}
+
+extern "C" int scat_preprocess_u8(const uint8_t* src, float* dst, int B, int SH, int SW, int OH, int OW, int hwc,
+                                  void* stream) {
+    SCAT_REQUIRE(src && dst && B > 0 && SH > 0 && SW > 0 && OH > 0 && OW > 0, SCAT_E_ARG,
+                 "scat_preprocess_u8: bad argument");
+    int64_t n = (int64_t)B * 3 * OH * OW;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n, SH, SW, OH,
+                       OW, hwc, (float)SH / OH, (float)SW / OW);
+    SCAT_LAUNCH_CHECK("scat_preprocess_u8");
+    return SCAT_OK;
 }
 
 extern "C" int scat_upsample_nearest_fwd(const float* x, float* y, int B, int C, int H, int W, int factor,

@@ -379,6 +379,17 @@ def tokens_bwd(dy, masked_idx, want_dmask=True):
     return dx, dm
 
 
+def preprocess_u8(src, out_hw=(224, 224), hwc=False):
+    """uint8 [B,3,H,W] (or [B,H,W,3] with hwc) on the GPU -> fp32 [B,3,224,224] in [-1,1], bilinear."""
+    if not (src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()):
+        raise ScatError("preprocess_u8 needs a contiguous uint8 GPU tensor")
+    B = src.shape[0]
+    SH, SW = (src.shape[1], src.shape[2]) if hwc else (src.shape[2], src.shape[3])
+    dst = torch.empty((B, 3, out_hw[0], out_hw[1]), dtype=torch.float32, device=src.device)
+    lib().scat_preprocess_u8(_p(src), _p(dst), B, SH, SW, out_hw[0], out_hw[1], int(hwc), _stream())
+    return dst
+
+
 def upsample_nearest_fwd(x, factor):
     _chk(x)
     B, C, H, W = x.shape

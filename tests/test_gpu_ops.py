@@ -295,3 +295,17 @@ def test_errors_are_loud(ops):
         ops.conv2d_fwd(x, torch.zeros(4, 3, 3, 3), 1, 1)  # CPU tensor: no fallback
     with pytest.raises(ScatError):
         ops.conv2d_fwd(g(x), g(torch.zeros(4, 3, 5, 5)), 1, 2)  # unsupported kernel size
+
+
+def test_preprocess_u8(ops):
+    """input pipeline kernel vs torch: /127.5-1 then bilinear(align_corners=False), CHW and HWC sources"""
+    u8 = torch.from_numpy(synth.randint_u8(60, "img", (3, 3, 256, 256)))
+    ref = F.interpolate(u8.float() / 127.5 - 1.0, size=(224, 224), mode="bilinear", align_corners=False)
+    assert rel_err(ops.preprocess_u8(u8.cuda()), ref) < 1e-5
+    hwc = u8.permute(0, 2, 3, 1).contiguous()
+    assert rel_err(ops.preprocess_u8(hwc.cuda(), hwc=True), ref) < 1e-5
+    same = torch.from_numpy(synth.randint_u8(61, "img", (2, 3, 224, 224)))
+    assert rel_err(ops.preprocess_u8(same.cuda()), same.float() / 127.5 - 1.0) < 1e-6
+    small = torch.from_numpy(synth.randint_u8(62, "img", (2, 3, 64, 64)))   # BASELINE configs[0]: 64x64 source
+    ref = F.interpolate(small.float() / 127.5 - 1.0, size=(224, 224), mode="bilinear", align_corners=False)
+    assert rel_err(ops.preprocess_u8(small.cuda()), ref) < 1e-5
