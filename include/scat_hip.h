@@ -48,6 +48,15 @@ int scat_conv2d_dgrad(const float* dy, const float* wt, float* dx, int B, int Ci
 int64_t scat_conv2d_dgrad_s2_ws(int Cin, int Cout, int KH, int KW);
 int scat_conv2d_dgrad_s2(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W, int Cout, int KH,
                          int KW, int pad, int accumulate, void* ws, int64_t ws_bytes, void* stream);
+/* 3x3 / stride 1 / pad 1 with an LDS-resident halo (every input element is fetched once per tile instead of
+ * once per tap): transposed = 0 -> dst[B,Cout,H,W] = conv(relu(src*scale+shift), w), src[B,Cin,H,W];
+ * transposed = 1 -> dst[B,Cin,H,W] (+)= data gradient from src = dy[B,Cout,H,W].  w is the forward weight
+ * [Cout,Cin,3,3]; ws: scat_conv3x3_s1_ws() bytes (re-laid weights).  Needs W <= 63.
+ * Replaces nn.Conv2d(3, padding=1) at models/resnet.py:68-69 and its autograd. */
+int64_t scat_conv3x3_s1_ws(int Cout, int Cin);
+int scat_conv3x3_s1(const float* src, const float* w, float* dst, int B, int Cin, int H, int W, int Cout,
+                    int transposed, const float* in_scale, const float* in_shift, int in_relu, int accumulate,
+                    void* ws, int64_t ws_bytes, void* stream);
 /* wt[Cin][Cout*KH*KW] = w[Cout][Cin][KH][KW] re-laid for the data-gradient contraction. */
 int scat_conv2d_wt(const float* w, float* wt, int Cout, int Cin, int KH, int KW, void* stream);
 /* dw[Cout,Cin,KH,KW] = sum over pixels dy * relu(x*scale+shift).  Deterministic two-stage

@@ -376,6 +376,90 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
 }
 
+// ---------------------------------------------------------------- epilogue
+// C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// Branch-free: 32-bit element offsets, raw buffer stores whose out-of-range lanes (tile edge) are
+// dropped by the hardware bounds check; the (accumulate, bias) variants are separate straight-line
+// copies selected once by uniform branches.
+template <int MI, int NI, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void store_tile(f32x16 (&acc)[MI][NI], const OutDesc& dc, int M, int N, int i0, int j0,
+                                           int z) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(dc.p + (dc.mode != 0 ? 0 : (int64_t)z * dc.sz), dc.n);
+    const int rstride = dc.mode != 0 ? dc.HW : (int)dc.si;
+    int coloff[NI];
+    bool colok[NI];
+    float bj[NI];
+#pragma unroll
+    for (int b = 0; b < NI; ++b) {
+        const int j = j0 + wn * (BN / WN) + b * 32 + l31;
+        colok[b] = j < N;
+        const int jc = colok[b] ? j : 0;
+        if (dc.mode == 1) {
+            uint32_t n = dc.dHW.div((uint32_t)jc);
+            coloff[b] = (int)n * dc.C * dc.HW + (jc - (int)n * dc.HW);
+        } else if (dc.mode == 2) {
+            uint32_t n = dc.dQHW.div((uint32_t)jc);
+            uint32_t r = jc - n * dc.dQHW.d;
+            uint32_t qy = dc.dQW.div(r), qx = r - qy * dc.QW;
+            coloff[b] = (int)n * dc.C * dc.HW + ((int)qy * dc.sub_s + dc.sub_y) * dc.W + (int)qx * dc.sub_s + dc.sub_x;
+        } else {
+            coloff[b] = jc * (int)dc.sj;
+        }
+        bj[b] = (dc.bias && dc.bias_mode == 2) ? dc.bias[jc] : 0.f;
+    }
+    const int ibase = i0 + wm * (BM / WM) + 4 * lh;
+    auto emit = [&](auto acc_tag, auto bias_tag) {
+        constexpr bool ACC = decltype(acc_tag)::value;
+        constexpr bool BIASI = decltype(bias_tag)::value;
+#pragma unroll
+        for (int a = 0; a < MI; ++a) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {          // 4 registers = 4 consecutive rows
+                int voff[4][NI];
+                float val[4][NI];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int i = ibase + a * 32 + rr + 8 * rq;
+                    const bool rowok = i < M;
+                    const float bi = BIASI ? dc.bias[rowok ? i : 0] : 0.f;
+#pragma unroll
+                    for (int b = 0; b < NI; ++b) {
+                        voff[rr][b] = (rowok && colok[b]) ? (coloff[b] + i * rstride) * 4 : OOB;
+                        val[rr][b] = acc[a][b][rq * 4 + rr] + bj[b] + bi;
+                    }
+                }
+                if constexpr (ACC) {
+                    float old[4][NI];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b) old[rr][b] = bload(rc, voff[rr][b]);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b) val[rr][b] += old[rr][b];
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int b = 0; b < NI; ++b)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[rr][b]), rc, voff[rr][b], 0, 0);
+            }
+        }
+    };
+    const bool biasi = dc.bias && dc.bias_mode == 1;
+    if (dc.accumulate) {
+        if (biasi) emit(std::true_type{}, std::true_type{});
+        else emit(std::true_type{}, std::false_type{});
+    } else {
+        if (biasi) emit(std::false_type{}, std::true_type{});
+        else emit(std::false_type{}, std::false_type{});
+    }
+}
+
 // PD = prefetch distance in K-steps.  PD = 1: the loads of step t+1 fly under the MFMAs of step t.
 // PD = 2: a second register set keeps the loads of step t+2 in flight as well (twice the bytes in flight per
 // CU — what the HBM-bound short-K layers need, MI355X wants >= 64 KiB in flight per CU to hide an HBM miss).
@@ -495,81 +579,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename
         }
     }
 
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    // Branch-free: 32-bit element offsets, raw buffer stores whose out-of-range lanes (tile edge) are
-    // dropped by the hardware bounds check; the (accumulate, bias) variants are separate straight-line
-    // copies selected once by uniform branches.
-    const __amdgpu_buffer_rsrc_t rc = make_rsrc(dc.p + (dc.mode != 0 ? 0 : (int64_t)z * dc.sz), dc.n);
-    const int rstride = dc.mode != 0 ? dc.HW : (int)dc.si;
-    int coloff[NI];
-    bool colok[NI];
-    float bj[NI];
-#pragma unroll
-    for (int b = 0; b < NI; ++b) {
-        const int j = j0 + wn * (BN / WN) + b * 32 + l31;
-        colok[b] = j < N;
-        const int jc = colok[b] ? j : 0;
-        if (dc.mode == 1) {
-            uint32_t n = dc.dHW.div((uint32_t)jc);
-            coloff[b] = (int)n * dc.C * dc.HW + (jc - (int)n * dc.HW);
-        } else if (dc.mode == 2) {
-            uint32_t n = dc.dQHW.div((uint32_t)jc);
-            uint32_t r = jc - n * dc.dQHW.d;
-            uint32_t qy = dc.dQW.div(r), qx = r - qy * dc.QW;
-            coloff[b] = (int)n * dc.C * dc.HW + ((int)qy * dc.sub_s + dc.sub_y) * dc.W + (int)qx * dc.sub_s + dc.sub_x;
-        } else {
-            coloff[b] = jc * (int)dc.sj;
-        }
-        bj[b] = (dc.bias && dc.bias_mode == 2) ? dc.bias[jc] : 0.f;
-    }
-    const int ibase = i0 + wm * (BM / WM) + 4 * lh;
-    auto emit = [&](auto acc_tag, auto bias_tag) {
-        constexpr bool ACC = decltype(acc_tag)::value;
-        constexpr bool BIASI = decltype(bias_tag)::value;
-#pragma unroll
-        for (int a = 0; a < MI; ++a) {
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {          // 4 registers = 4 consecutive rows
-                int voff[4][NI];
-                float val[4][NI];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int i = ibase + a * 32 + rr + 8 * rq;
-                    const bool rowok = i < M;
-                    const float bi = BIASI ? dc.bias[rowok ? i : 0] : 0.f;
-#pragma unroll
-                    for (int b = 0; b < NI; ++b) {
-                        voff[rr][b] = (rowok && colok[b]) ? (coloff[b] + i * rstride) * 4 : OOB;
-                        val[rr][b] = acc[a][b][rq * 4 + rr] + bj[b] + bi;
-                    }
-                }
-                if constexpr (ACC) {
-                    float old[4][NI];
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                        for (int b = 0; b < NI; ++b) old[rr][b] = bload(rc, voff[rr][b]);
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                        for (int b = 0; b < NI; ++b) val[rr][b] += old[rr][b];
-                }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                    for (int b = 0; b < NI; ++b)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[rr][b]), rc, voff[rr][b], 0, 0);
-            }
-        }
-    };
-    const bool biasi = dc.bias && dc.bias_mode == 1;
-    if (dc.accumulate) {
-        if (biasi) emit(std::true_type{}, std::true_type{});
-        else emit(std::true_type{}, std::false_type{});
-    } else {
-        if (biasi) emit(std::false_type{}, std::true_type{});
-        else emit(std::false_type{}, std::false_type{});
-    }
+    store_tile<MI, NI, BM, BN, WM, WN>(acc, dc, M, N, i0, j0, z);
 }
 
 // deterministic split-K combine: out[e] (+)= sum_z slab[z][e], fixed order

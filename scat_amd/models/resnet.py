@@ -60,6 +60,20 @@ class _BNState:
             self.mean = self.invstd = None
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    """One side stream per device for the weight-gradient contractions (SCAT_SIDE_WGRAD=0 disables)."""
+    import os
+    if os.environ.get("SCAT_SIDE_WGRAD", "1") == "0":
+        return None
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 class _BackboneFn(torch.autograd.Function):
     """ResNet.forward (models/resnet.py:142-162) + its whole backward as one node."""
 
@@ -131,6 +145,27 @@ class _BackboneFn(torch.autograd.Function):
         def put(p, g):
             grads[p] = g
 
+        # Weight gradients are off the critical path (nothing in this backward reads them): they run on a side
+        # stream, so their ramp-up/tail and the HBM-bound BatchNorm passes of the next layer overlap.
+        main = torch.cuda.current_stream()
+        side = _side_stream(dfeat.device if dfeat is not None else outs[0].device)
+
+        def wgrad(dy, x, w, stride, pad, sc=None, sh=None, relu=False):
+            out = gbuf(w)
+            if side is None:
+                return ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, sc, sh, relu, out=out)
+            if out is None:
+                out = torch.empty_like(w)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, sc, sh, relu, out=out, ws_slot="side")
+            dy.record_stream(side)
+            return out
+
+        def join():
+            if side is not None:
+                main.wait_stream(side)
+
         stage_grads = [dx1, dx2, dx3, dx4]
         # ---- tail: relu(fc1(relu(avgpool(x4))))
         x4 = tape[-1][-1]
@@ -158,28 +193,25 @@ class _BackboneFn(torch.autograd.Function):
                                      gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), dres=dcur)
             put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
             g = dcur
-            put(blk.conv3.weight, ops.conv2d_wgrad(dc3, c2, tuple(blk.conv3.weight.shape), 1, 0, s2.scale, s2.shift,
-                                                   True, out=gbuf(blk.conv3.weight)))
+            put(blk.conv3.weight, wgrad(dc3, c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True))
             da2 = ops.conv2d_dgrad_w(dc3, blk.conv3.weight, tuple(c2.shape), 1, 0)
             del dc3
             dc2, dg, db = ops.bn_bwd(da2, c2, None, True, s2.scale, s2.shift, s2.mean, s2.invstd, blk.bn2.weight,
                                      gbuf(blk.bn2.weight), gbuf(blk.bn2.bias), dx=da2)
             put(blk.bn2.weight, dg), put(blk.bn2.bias, db)
-            put(blk.conv2.weight, ops.conv2d_wgrad(dc2, c1, tuple(blk.conv2.weight.shape), blk.stride, 1, s1.scale,
-                                                   s1.shift, True, out=gbuf(blk.conv2.weight)))
+            put(blk.conv2.weight, wgrad(dc2, c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True))
             da1 = ops.conv2d_dgrad_w(dc2, blk.conv2.weight, tuple(c1.shape), blk.stride, 1)
             del dc2, da2
             dc1, dg, db = ops.bn_bwd(da1, c1, None, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight,
                                      gbuf(blk.bn1.weight), gbuf(blk.bn1.bias), dx=da1)
             put(blk.bn1.weight, dg), put(blk.bn1.bias, db)
-            put(blk.conv1.weight, ops.conv2d_wgrad(dc1, xin, tuple(blk.conv1.weight.shape), 1, 0,
-                                                   out=gbuf(blk.conv1.weight)))
+            put(blk.conv1.weight, wgrad(dc1, xin, blk.conv1.weight, 1, 0))
             if cd is not None:
                 dsw, dsbn = blk.downsample[0].weight, blk.downsample[1]
                 dcd, dg, db = ops.bn_bwd(g, cd, None, False, sd.scale, sd.shift, sd.mean, sd.invstd, dsbn.weight,
                                          gbuf(dsbn.weight), gbuf(dsbn.bias), dx=g)
                 put(dsbn.weight, dg), put(dsbn.bias, db)
-                put(dsw, ops.conv2d_wgrad(dcd, xin, tuple(dsw.shape), blk.stride, 0, out=gbuf(dsw)))
+                put(dsw, wgrad(dcd, xin, dsw, blk.stride, 0))
                 dxin = ops.conv2d_dgrad_w(dcd, dsw, tuple(xin.shape), blk.stride, 0)
                 del dcd
             else:
@@ -189,6 +221,7 @@ class _BackboneFn(torch.autograd.Function):
             remaining -= 1
             if remaining == 0:
                 if sink is not None:
+                    join()       # the all-reduce stream orders itself after the CURRENT stream only
                     sink.ready(("layer%d" % (li + 1),))
                 li -= 1
                 if li >= 0:
@@ -202,8 +235,8 @@ class _BackboneFn(torch.autograd.Function):
         dc0, dg, db = ops.bn_bwd(da0, c0, None, True, s0.scale, s0.shift, s0.mean, s0.invstd, net.bn1.weight,
                                  gbuf(net.bn1.weight), gbuf(net.bn1.bias), dx=da0)
         put(net.bn1.weight, dg), put(net.bn1.bias, db)
-        put(net.conv1.weight, ops.conv2d_wgrad(dc0, x, tuple(net.conv1.weight.shape), 2, 3,
-                                               out=gbuf(net.conv1.weight)))
+        put(net.conv1.weight, wgrad(dc0, x, net.conv1.weight, 2, 3))
+        join()
         ctx.tape = ctx.stem = ctx.tail = None
         # the input image needs no gradient on this path (train.py feeds data, not a leaf)
         if sink is not None:

@@ -6,6 +6,8 @@ caller-owned buffers. There is no fallback path: tensors must be fp32, contiguou
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ._lib import ScatError, lib
@@ -62,12 +64,24 @@ def conv_out_hw(H, W, k, stride, pad):
     return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
 
 
+HALO = os.environ.get("SCAT_HALO", "1") != "0"   # 3x3/s1/p1 through the LDS-halo kernel (0: generic gather, for A/B runs)
+
+
+def _halo_ok(KH, KW, stride, pad, csrc, W):
+    return HALO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and W <= 63
+
+
 def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, bias=None, out=None):
     _chk(x, w, in_scale, in_shift, bias)
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
     OH, OW = conv_out_hw(H, W, KH, stride, pad)
     y = out if out is not None else torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    if _halo_ok(KH, KW, stride, pad, Cin, W) and bias is None:
+        ws = workspace(lib().scat_conv3x3_s1_ws(Cout, Cin), x.device, "wt")
+        _prof(2.0 * B * OH * OW * Cout * Cin * 9, lib().scat_conv3x3_s1, _p(x), _p(w), _p(y), B, Cin, H, W, Cout, 0,
+              _p(in_scale), _p(in_shift), int(in_relu), 0, _p(ws), ws.numel(), _stream())
+        return y
     _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_fwd, _p(x), _p(w), _p(bias), _p(y), B, Cin, H, W,
           Cout, KH, KW, stride, pad, _p(in_scale), _p(in_shift), int(in_relu), _stream())
     return y
@@ -105,18 +119,25 @@ def conv2d_dgrad_w(dy, w, x_shape, stride, pad, out=None, accumulate=False):
         _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_dgrad_s2, _p(dy), _p(w), _p(dx), B, Cin, H,
               W, Cout, KH, KW, pad, int(accumulate), _p(ws), ws.numel(), _stream())
         return dx
+    if _halo_ok(KH, KW, stride, pad, Cout, W):
+        dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+        ws = workspace(lib().scat_conv3x3_s1_ws(Cout, Cin), dy.device, "wt")
+        _prof(2.0 * B * H * W * Cout * Cin * 9, lib().scat_conv3x3_s1, _p(dy), _p(w), _p(dx), B, Cin, H, W, Cout, 1,
+              0, 0, 0, int(accumulate), _p(ws), ws.numel(), _stream())
+        return dx
     wt = conv2d_wt(w, out=workspace(4 * w.numel(), dy.device, "wt")[: 4 * w.numel()].view(torch.float32)
                    .view(Cin, Cout * KH * KW))
     return conv2d_dgrad(dy, wt, x_shape, tuple(w.shape), stride, pad, out=out, accumulate=accumulate)
 
 
-def conv2d_wgrad(dy, x, w_shape, stride, pad, in_scale=None, in_shift=None, in_relu=False, out=None):
+def conv2d_wgrad(dy, x, w_shape, stride, pad, in_scale=None, in_shift=None, in_relu=False, out=None,
+                 ws_slot="default"):
     _chk(dy, x, in_scale, in_shift, out)
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w_shape
     dw = out if out is not None else torch.empty(w_shape, dtype=torch.float32, device=x.device)
     need = lib().scat_conv2d_wgrad_ws(B, Cin, H, W, Cout, KH, KW, stride, pad)
-    ws = workspace(need, x.device)
+    ws = workspace(need, x.device, ws_slot)
     OH, OW = conv_out_hw(H, W, KH, stride, pad)
     _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_wgrad, _p(dy), _p(x), _p(dw), B, Cin, H, W,
           Cout, KH, KW, stride, pad, _p(in_scale), _p(in_shift), int(in_relu), _p(ws), ws.numel(), _stream())

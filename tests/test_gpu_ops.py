@@ -100,6 +100,40 @@ def test_dgrad_s2_odd_sizes(ops, H, W):
         assert rel_err(ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 2, p), dx_ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 20, 72, 9, 13), (1, 16, 200, 5, 63), (3, 36, 64, 7, 7),
+                                             (2, 64, 132, 30, 4), (5, 128, 128, 14, 14)])
+def test_conv3x3_halo(ops, B, cin, cout, H, W):
+    """3x3/s1/p1 LDS-halo kernel: ragged channel counts (C % 16 != 0, Cout % 64 != 0), tiles that straddle
+    images, rows shorter than the pixel vector, the widest supported row; forward (+fused input transform)
+    and data gradient (+accumulate) against fp64 torch and against the generic gather kernel."""
+    assert ops.HALO
+    x = t(60, "x", (B, cin, H, W)).requires_grad_(True)
+    w = t(61, "w", (cout, cin, 3, 3), std=(2.0 / (cin * 9)) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x.double(), w.double(), padding=1)
+    dy = t(62, "dy", tuple(y.shape))
+    (dx_ref,) = torch.autograd.grad(y, x, dy.double())
+    yg = ops.conv2d_fwd(g(x.detach()), g(w.detach()), 1, 1)
+    assert ops.lib().scat_last_kernel().decode().startswith("conv3x3_halo")
+    assert rel_err(yg, y) < 2e-5
+    dxg = ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 1, 1)
+    assert ops.lib().scat_last_kernel().decode().startswith("conv3x3_halo")
+    assert rel_err(dxg, dx_ref) < 2e-5
+    base = g(t(63, "acc", tuple(x.shape)))
+    dxa = ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 1, 1, out=base.clone(), accumulate=True)
+    assert rel_err(dxa, dx_ref + base.cpu().double()) < 2e-5
+    sc = torch.from_numpy(synth.uniform(64, "sc", (cin,), 0.5, 1.5))
+    sh = torch.from_numpy(synth.uniform(65, "sh", (cin,), -0.5, 0.5))
+    a = F.relu(x.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    yt = F.conv2d(a.double(), w.detach().double(), padding=1)
+    ytg = ops.conv2d_fwd(g(x.detach()), g(w.detach()), 1, 1, g(sc), g(sh), True)
+    assert rel_err(ytg, yt) < 2e-5
+    try:      # same answers as the generic gather path
+        ops.HALO = False
+        assert rel_err(ops.conv2d_fwd(g(x.detach()), g(w.detach()), 1, 1, g(sc), g(sh), True), ytg.cpu()) < 2e-5
+    finally:
+        ops.HALO = True
+
+
 def test_conv_bias_and_edge_batches(ops):
     for B in (1, 5):
         x = t(10, "x", (B, 20, 9, 9))
