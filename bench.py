@@ -84,11 +84,16 @@ def dominant_kernel_roofline(ts, x, lab):
     """One extra instrumented step (outside the timed region): HIP events around every launch of the
     contraction engine, grouped by kernel instantiation; report the one with the most total time."""
     from scat_amd import ops
+    from scat_amd.models import resnet as resnet_mod
 
+    # per-kernel durations are only meaningful when kernels do not share the GPU: this one step runs the
+    # weight gradients on the main stream instead of the side stream (the timed steps overlap them)
+    side, resnet_mod.SIDE_WGRAD = resnet_mod.SIDE_WGRAD, False
     ops.PROFILE = []
     ts(x, lab)
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
+    resnet_mod.SIDE_WGRAD = side
     agg = {}
     for name, flops, e0, e1 in rec:
         ms = e0.elapsed_time(e1)

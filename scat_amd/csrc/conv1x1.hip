@@ -1,0 +1,260 @@
+// Pointwise (1x1, stride 1) convolution forward / data-gradient:  dst[n][m][r] = sum_c A[m][c] * f(src[n][c][r]).
+//
+// Same operand split as conv3x3.hip, which measured ~15 % faster than staging both operands through LDS:
+//  * A (weights [M][K], K contiguous, L2-resident) goes straight from global memory to the MFMA operand
+//    registers.  The contraction order inside a 16-channel sub-chunk is free, so lane (row, h) takes
+//    k = 8h .. 8h+7: 32 contiguous bytes, two 16-B loads, prefetched one sub-chunk ahead.
+//  * B (activations) is staged through LDS 32 channels at a time in k-pair-interleaved rows
+//    [k/2][pixel][k&1]: a staging thread owns a channel PAIR x 4 pixels (two 16-B global loads -> two
+//    ds_write_b128) and a lane reads its k pair with one ds_read_b64.  The fused BatchNorm+ReLU of the
+//    producing layer is applied once per element on the way into LDS.
+//  * one barrier per 32 channels (64 MFMAs per wave at 128x128); fragments of the second sub-chunk are
+//    read while the first one computes.
+//
+// Replaces nn.Conv2d(k=1) and its input gradient as called at models/resnet.py:65-67,70-72,84-92 of the
+// reference (conv1/conv3 of every Bottleneck) and the 1x1 reductions of models/hand_net.py, fp32.
+#include "conv_common.h"
+
+namespace scat {
+
+struct PwDesc {
+    const float* src;     // [Nimg][C][HW]
+    const float* w;       // [M][C]
+    const float* scale;   // optional fused input transform, per source channel
+    const float* shift;
+    int relu;
+    int C, M, HW, npix;
+    FastDiv dHW;
+    int64_t nsrc, nw;
+};
+
+constexpr int PW_KS = 32;     // channels per LDS stage (two 16-channel sub-chunks)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, bool V4, bool TF>
+__global__ __launch_bounds__(NT, (BM * BN >= 128 * 128 ? 2 : 3)) void conv1x1_kernel(PwDesc d, OutDesc dc) {
+    constexpr int MI = BM / 64, NI = BN / 64;
+    constexpr int PV = V4 ? 4 : 1;                    // pixels per staging item
+    constexpr int PT = BN / PV;                       // staging threads along the pixel dimension
+    constexpr int NIT = 16 * PT / NT;                 // staging items (channel pair x PV pixels) per thread
+    static_assert(NIT >= 1, "tile too small for 256 staging threads");
+    extern __shared__ __align__(16) float lds[];      // B[2][16 k-pairs][BN][2]
+    auto Bs = [&](int buf) -> float* { return lds + buf * (PW_KS * BN); };
+
+    const int mt = (d.M + BM - 1) / BM, nt = (d.npix + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int i0 = (tile % mt) * BM, j0 = (tile / mt) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nstage = (d.C + PW_KS - 1) / PW_KS;
+
+    // ---- activation staging: item r of this thread = channel pair p = tid/PT + r*(NT/PT), pixels (tid%PT)*PV ..
+    const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(d.src, d.nsrc);
+    const __amdgpu_buffer_rsrc_t rsrc_sc = make_rsrc(TF ? d.scale : d.src, TF ? d.C : 0);
+    const __amdgpu_buffer_rsrc_t rsrc_sh = make_rsrc(TF ? d.shift : d.src, TF ? d.C : 0);
+    const int pcol = (tid % PT) * PV, prow = tid / PT;
+    const int chw4 = d.HW * 4;
+    int boff;                                          // byte offset of (n, channel 2*prow, r) or OOB
+    bool bok;
+    {
+        const int j = j0 + pcol;
+        bok = j < d.npix;
+        const uint32_t jj = bok ? (uint32_t)j : 0u;
+        const uint32_t n = d.dHW.div(jj);
+        boff = bok ? (int)((n * (uint32_t)d.C * (uint32_t)d.HW + (jj - n * (uint32_t)d.HW)) * 4u) + 2 * prow * chw4 : OOB;
+    }
+    float bst[NIT][2][PV];
+    f32x2 tsc[TF ? NIT : 1], tsh[TF ? NIT : 1];
+    auto load_b = [&](int c0) {                        // channels >= C read 0 (also the prefetch past the end)
+#pragma unroll
+        for (int r = 0; r < NIT; ++r) {
+            const int c = c0 + 2 * (prow + r * (NT / PT));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int vo = c + u < d.C ? boff : OOB;
+                const int so = (c0 + 2 * r * (NT / PT) + u) * chw4;
+                if constexpr (V4) {
+                    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vo, so, 0);
+                    bst[r][u][0] = __uint_as_float(t.x); bst[r][u][1] = __uint_as_float(t.y);
+                    bst[r][u][2] = __uint_as_float(t.z); bst[r][u][3] = __uint_as_float(t.w);
+                } else {
+                    bst[r][u][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_b, vo, so, 0));
+                }
+            }
+            if constexpr (TF) {                        // scale/shift of the pair (c even, C even: 8-B load)
+                const int vo = c < d.C ? c * 4 : OOB;
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rsrc_sc, vo, 0, 0);
+                u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rsrc_sh, vo, 0, 0);
+                tsc[r] = f32x2{__uint_as_float(a.x), __uint_as_float(a.y)};
+                tsh[r] = f32x2{__uint_as_float(b.x), __uint_as_float(b.y)};
+            }
+        }
+    };
+    auto store_b = [&](float* dst) {
+#pragma unroll
+        for (int r = 0; r < NIT; ++r) {
+            float x[2][PV];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int q = 0; q < PV; ++q) {
+                    float t = bst[r][u][q];
+                    if constexpr (TF) {
+                        t = fmaf(t, tsc[r][u], tsh[r][u]);
+                        t = d.relu ? fmaxf(t, 0.f) : t;
+                        t = bok ? t : 0.f;             // out-of-range pixels / channels (scale, shift read 0 there)
+                    }
+                    x[u][q] = t;
+                }
+            float* p = dst + ((prow + r * (NT / PT)) * BN + pcol) * 2;
+            if constexpr (V4) {
+                *(f32x4*)p = f32x4{x[0][0], x[1][0], x[0][1], x[1][1]};
+                *(f32x4*)(p + 4) = f32x4{x[0][2], x[1][2], x[0][3], x[1][3]};
+            } else {
+                *(f32x2*)p = f32x2{x[0][0], x[1][0]};
+            }
+        }
+    };
+
+    // ---- weights: lane (row, h) holds k = 8h .. 8h+7 of its rows, straight from global memory
+    const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(d.w, d.nw);
+    int aoff[MI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a) {
+        const int row = i0 + wm * (BM / 2) + a * 32 + l31;
+        aoff[a] = row < d.M ? (row * d.C + lh * 8) * 4 : OOB;
+    }
+    auto load_a = [&](float (&dst)[MI][8], int c) {   // c >= C: zeros
+#pragma unroll
+        for (int a = 0; a < MI; ++a) {
+            const int vo = c < d.C ? aoff[a] : OOB;
+            u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, c * 4, 0);
+            u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo + 16, c * 4, 0);
+            dst[a][0] = __uint_as_float(t0.x); dst[a][1] = __uint_as_float(t0.y);
+            dst[a][2] = __uint_as_float(t0.z); dst[a][3] = __uint_as_float(t0.w);
+            dst[a][4] = __uint_as_float(t1.x); dst[a][5] = __uint_as_float(t1.y);
+            dst[a][6] = __uint_as_float(t1.z); dst[a][7] = __uint_as_float(t1.w);
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // B fragments of sub-chunk t: NI pixels x 4 k-pairs, 8 bytes each (rows t*8 + 4h + jp)
+    const int b_frag = lh * 4 * BN + wn * (BN / 2) + l31;
+    auto read_b = [&](f32x2 (&dst)[NI][4], const float* buf, int t) {
+        const f32x2* p = (const f32x2*)buf + t * 8 * BN + b_frag;
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) dst[b][jp] = p[jp * BN + b * 32];
+    };
+    float areg[2][MI][8];
+    f32x2 breg[2][NI][4];
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[set][a][j], breg[set][b][j >> 1][j & 1],
+                                                                     acc[a][b], 0, 0, 0);
+    };
+
+    load_b(0);
+    load_a(areg[0], 0);
+    store_b(Bs(0));
+    __syncthreads();
+    read_b(breg[0], Bs(0), 0);
+
+    for (int s = 0; s < nstage; ++s) {
+        const int c0 = s * PW_KS;
+        const float* bcur = Bs(s & 1);
+        float* bnext = Bs((s + 1) & 1);
+        // sub-chunk 0: start the next stage's activations and this stage's second half
+        load_b(c0 + PW_KS);
+        load_a(areg[1], c0 + 16);
+        read_b(breg[1], bcur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // sub-chunk 1
+        load_a(areg[0], c0 + PW_KS);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_b(bnext);
+        __syncthreads();
+        read_b(breg[0], bnext, 0);
+    }
+    store_tile<MI, NI, BM, BN, 2, 2>(acc, dc, d.M, d.npix, i0, j0, 0);
+}
+
+template <int BM, int BN, bool V4, bool TF>
+static void launch_pw(const PwDesc& d, const OutDesc& dc, hipStream_t st) {
+    const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, BN);
+    constexpr size_t lds_bytes = sizeof(float) * 2 * PW_KS * BN;
+    hipLaunchKernelGGL((conv1x1_kernel<BM, BN, V4, TF>), dim3(mt * nt), dim3(NT), lds_bytes, st, d, dc);
+}
+
+template <bool V4, bool TF>
+static void launch_pw_cfg(int cfg, const PwDesc& d, const OutDesc& dc, hipStream_t st) {
+    if (cfg == 0) launch_pw<128, 128, V4, TF>(d, dc, st);
+    else if (cfg == 1) launch_pw<64, 128, V4, TF>(d, dc, st);
+    else launch_pw<64, 64, V4, TF>(d, dc, st);
+}
+
+}  // namespace scat
+
+using namespace scat;
+
+// dst[B,M,HW] (+)= A[M,C] . f(src[B,C,HW]),  f = relu(x*scale+shift) when scale is given.
+//   forward:        A = w[Cout][Cin]            (C = Cin,  M = Cout)
+//   data gradient:  A = scat_conv2d_wt(w) = [Cin][Cout], src = dy   (C = Cout, M = Cin)
+// Needs C % 16 == 0 and 16-B aligned A; callers fall back to scat_conv2d_fwd / scat_conv2d_dgrad otherwise.
+extern "C" int scat_conv1x1_s1(const float* src, const float* a, float* dst, int B, int C, int HW, int M,
+                               const float* bias, const float* in_scale, const float* in_shift, int in_relu,
+                               int accumulate, void* stream) {
+    SCAT_REQUIRE(src && a && dst, SCAT_E_ARG, "scat_conv1x1_s1: null pointer");
+    SCAT_REQUIRE(B > 0 && C > 0 && HW > 0 && M > 0, SCAT_E_SHAPE, "scat_conv1x1_s1: non-positive dimension");
+    SCAT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), SCAT_E_ARG, "scat_conv1x1_s1: scale/shift pair");
+    SCAT_REQUIRE(C % 16 == 0, SCAT_E_SHAPE, "scat_conv1x1_s1: channels must be a multiple of 16");
+    SCAT_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)src & 15) == 0, SCAT_E_ARG, "scat_conv1x1_s1: 16-B alignment");
+    SCAT_REQUIRE(!in_scale || (((uintptr_t)in_scale & 7) == 0 && ((uintptr_t)in_shift & 7) == 0), SCAT_E_ARG,
+                 "scat_conv1x1_s1: scale/shift must be 8-B aligned");
+    SCAT_REQUIRE(fits_i32((int64_t)B * C * HW * 4) && fits_i32((int64_t)B * M * HW * 4) && fits_i32((int64_t)M * C * 4),
+                 SCAT_E_SHAPE, "scat_conv1x1_s1: tensor exceeds 32-bit byte offsets");
+    hipStream_t st = (hipStream_t)stream;
+    PwDesc d{};
+    d.src = src; d.w = a; d.scale = in_scale; d.shift = in_shift; d.relu = in_scale ? in_relu : 0;
+    d.C = C; d.M = M; d.HW = HW; d.npix = B * HW; d.dHW = FastDiv::make(HW);
+    d.nsrc = (int64_t)B * C * HW; d.nw = (int64_t)M * C;
+    OutDesc dc{};
+    dc.p = dst; dc.mode = 1; dc.I = M; dc.J = d.npix; dc.C = M; dc.HW = HW; dc.dHW = FastDiv::make(HW);
+    dc.bias = bias; dc.bias_mode = bias ? 1 : 0; dc.accumulate = accumulate; dc.n = (int64_t)B * M * HW;
+    auto tiles = [&](int bm, int bn) { return (int64_t)cdiv(M, bm) * cdiv(d.npix, bn); };
+    int cfg = (M > 64 && tiles(128, 128) >= 1024) ? 0 : 2;   // measured: 64x128 never wins at batch 96
+    if (tuning() >= 1 && tuning() <= 3) cfg = tuning() - 1;
+    static const char* const names[] = {"128x128", "64x128", "64x64"};
+    const bool v4 = HW % 4 == 0;
+    set_kernel_label("conv1x1_pw_%sx32%s%s", names[cfg], v4 ? "_b4" : "", in_scale ? "_tf" : "");
+    if (v4) {
+        if (in_scale) launch_pw_cfg<true, true>(cfg, d, dc, st);
+        else launch_pw_cfg<true, false>(cfg, d, dc, st);
+    } else {
+        if (in_scale) launch_pw_cfg<false, true>(cfg, d, dc, st);
+        else launch_pw_cfg<false, false>(cfg, d, dc, st);
+    }
+    SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
+    return SCAT_OK;
+}

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 }
 
 // gather form (no atomics): an input pixel sums the windows whose arg-max it is.
-// grid.y = (n,c) plane, threads sweep the plane: no integer divisions by runtime sizes except one per pixel row.
+// generic sizes: grid.y = (n,c) plane, threads sweep the plane.
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
                                                           const int8_t* __restrict__ idx, float* __restrict__ dx,
                                                           int H, int W, int OH, int OW) {
@@ -63,6 +63,49 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
             }
         }
         o[e] = s;
+    }
+}
+
+// even H, W with W % 4 == 0 (the stem: 112x112 -> 56x56).  Input row 2a / column 2b is seen by one window
+// row / column (tap 1), the odd ones by two (tap 2 of window a, tap 0 of window a+1), so a 2x2 input quad
+// depends on the 2x2 windows (a..a+1, b..b+1) only.  One thread = two horizontally adjacent quads:
+// 6 window reads (shared with the neighbours through L1), two 16-B stores.
+__global__ __launch_bounds__(256) void maxpool_bwd_quad_kernel(const float* __restrict__ dy,
+                                                               const int8_t* __restrict__ idx,
+                                                               float* __restrict__ dx, int64_t total, int W,
+                                                               int OH, int OW) {
+    const int QW = OW / 2;
+    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+        const int b2 = e % QW;
+        const int64_t r = e / QW;
+        const int a = r % OH;
+        const int64_t nc = r / OH;
+        const float* g = dy + nc * OH * OW;
+        const int8_t* id = idx + nc * OH * OW;
+        const int b = 2 * b2;
+        float gv[2][3];
+        int iv[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const bool ok = (a + u < OH) && (b + v < OW);
+                const int q = ok ? (a + u) * OW + b + v : 0;
+                gv[u][v] = ok ? g[q] : 0.f;
+                iv[u][v] = ok ? (int)id[q] : -1;
+            }
+        float top[4], bot[4];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {   // quad v uses window columns v, v+1
+            top[2 * v] = iv[0][v] == 4 ? gv[0][v] : 0.f;
+            top[2 * v + 1] = (iv[0][v] == 5 ? gv[0][v] : 0.f) + (iv[0][v + 1] == 3 ? gv[0][v + 1] : 0.f);
+            bot[2 * v] = (iv[0][v] == 7 ? gv[0][v] : 0.f) + (iv[1][v] == 1 ? gv[1][v] : 0.f);
+            bot[2 * v + 1] = (iv[0][v] == 8 ? gv[0][v] : 0.f) + (iv[0][v + 1] == 6 ? gv[0][v + 1] : 0.f) +
+                             (iv[1][v] == 2 ? gv[1][v] : 0.f) + (iv[1][v + 1] == 0 ? gv[1][v + 1] : 0.f);
+        }
+        float* o = dx + (nc * 2 * OH + 2 * a) * W + 2 * b;
+        *(float4*)o = make_float4(top[0], top[1], top[2], top[3]);
+        *(float4*)(o + W) = make_float4(bot[0], bot[1], bot[2], bot[3]);
     }
 }
 
@@ -117,6 +160,13 @@ extern "C" int scat_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* 
     SCAT_REQUIRE(dy && idx && dx, SCAT_E_ARG, "scat_maxpool3x3s2_bwd: null pointer");
     SCAT_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, SCAT_E_SHAPE, "scat_maxpool3x3s2_bwd: non-positive dimension");
     int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    if (H % 2 == 0 && W % 4 == 0 && ((uintptr_t)dx & 15) == 0) {
+        const int64_t total = (int64_t)B * C * OH * (OW / 2);
+        hipLaunchKernelGGL(maxpool_bwd_quad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, idx,
+                           dx, total, W, OH, OW);
+        SCAT_LAUNCH_CHECK("scat_maxpool3x3s2_bwd");
+        return SCAT_OK;
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(cdiv((int64_t)H * W, 256 * 4), B * C), dim3(256), 0,
                        (hipStream_t)stream, dy, idx, dx, H, W, OH, OW);
     SCAT_LAUNCH_CHECK("scat_maxpool3x3s2_bwd");

@@ -104,13 +104,17 @@ class GradBuckets:
     def begin_backbone(self):
         """Called at the top of the backbone backward: head gradients are final by then (every head node is
         nearer the loss than the backbone).  Gather them into the flat buffer and reduce them first."""
+        dst, src = [], []
         for p in self.head_params:
             v = self.view_for(p)
             if p.grad is None:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
+                dst.append(v)
+                src.append(p.grad)
             p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)   # one multi-tensor launch instead of one copy per parameter
         self._allreduce(self.grad_slice("head"))
         self._head_sent = True
 

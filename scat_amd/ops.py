@@ -71,12 +71,27 @@ def _halo_ok(KH, KW, stride, pad, csrc, W):
     return HALO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and W <= 63
 
 
+PW_MIN_C = int(os.environ.get("SCAT_PW_MIN_C", "512"))
+PW = os.environ.get("SCAT_PW", "1") != "0"       # 1x1/s1 through the weights-in-registers kernel (0: generic gather)
+
+
+def _pw_ok(KH, KW, stride, pad, csrc, *ts):
+    # measured (tools/conv_bench.py, batch 96): ahead of the generic engine from 512 contraction channels up,
+    # behind it on the short, store-bound contractions of layer1/layer2 (PW_MIN_C=0 forces it, for tests)
+    return (PW and KH == 1 and KW == 1 and stride == 1 and pad == 0 and csrc % 16 == 0 and csrc >= PW_MIN_C
+            and all(t is None or t.data_ptr() % 16 == 0 for t in ts))
+
+
 def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, bias=None, out=None):
     _chk(x, w, in_scale, in_shift, bias)
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
     OH, OW = conv_out_hw(H, W, KH, stride, pad)
     y = out if out is not None else torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    if _pw_ok(KH, KW, stride, pad, Cin, x, w, in_scale, in_shift):
+        _prof(2.0 * B * OH * OW * Cout * Cin, lib().scat_conv1x1_s1, _p(x), _p(w), _p(y), B, Cin, H * W, Cout, _p(bias),
+              _p(in_scale), _p(in_shift), int(in_relu), 0, _stream())
+        return y
     if _halo_ok(KH, KW, stride, pad, Cin, W) and bias is None:
         ws = workspace(lib().scat_conv3x3_s1_ws(Cout, Cin), x.device, "wt")
         _prof(2.0 * B * OH * OW * Cout * Cin * 9, lib().scat_conv3x3_s1, _p(x), _p(w), _p(y), B, Cin, H, W, Cout, 0,
@@ -127,6 +142,11 @@ def conv2d_dgrad_w(dy, w, x_shape, stride, pad, out=None, accumulate=False):
         return dx
     wt = conv2d_wt(w, out=workspace(4 * w.numel(), dy.device, "wt")[: 4 * w.numel()].view(torch.float32)
                    .view(Cin, Cout * KH * KW))
+    if _pw_ok(KH, KW, stride, pad, Cout, dy, wt, out):
+        dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+        _prof(2.0 * B * H * W * Cout * Cin, lib().scat_conv1x1_s1, _p(dy), _p(wt), _p(dx), B, Cout, H * W, Cin, 0, 0, 0,
+              0, int(accumulate), _stream())
+        return dx
     return conv2d_dgrad(dy, wt, x_shape, tuple(w.shape), stride, pad, out=out, accumulate=accumulate)
 
 

@@ -134,6 +134,42 @@ def test_conv3x3_halo(ops, B, cin, cout, H, W):
         ops.HALO = True
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 48, 80, 9, 13), (1, 16, 208, 5, 64), (3, 32, 64, 7, 7),
+                                             (2, 64, 144, 30, 4), (5, 256, 128, 14, 14)])
+def test_conv1x1_pointwise(ops, monkeypatch, B, cin, cout, H, W):
+    """1x1/s1 weights-in-registers kernel: vector and scalar pixel staging (HW % 4), channel counts that are
+    odd multiples of 16, ragged row/pixel tiles; forward (+bias, +fused input transform) and data gradient
+    (+accumulate) against fp64 torch and against the generic gather kernel."""
+    assert ops.PW
+    monkeypatch.setattr(ops, "PW_MIN_C", 0)
+    x = t(70, "x", (B, cin, H, W)).requires_grad_(True)
+    w = t(71, "w", (cout, cin, 1, 1), std=(2.0 / cin) ** 0.5).requires_grad_(True)
+    bias = t(72, "b", (cout,))
+    y = F.conv2d(x.double(), w.double(), bias.double())
+    dy = t(73, "dy", tuple(y.shape))
+    (dx_ref,) = torch.autograd.grad(y, x, dy.double())
+    yg = ops.conv2d_fwd(g(x.detach()), g(w.detach()), 1, 0, bias=g(bias))
+    assert ops.lib().scat_last_kernel().decode().startswith("conv1x1_pw")
+    assert rel_err(yg, y) < 2e-5
+    dxg = ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 1, 0)
+    assert ops.lib().scat_last_kernel().decode().startswith("conv1x1_pw")
+    assert rel_err(dxg, dx_ref) < 2e-5
+    base = g(t(74, "acc", tuple(x.shape)))
+    dxa = ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 1, 0, out=base.clone(), accumulate=True)
+    assert rel_err(dxa, dx_ref + base.cpu().double()) < 2e-5
+    sc = torch.from_numpy(synth.uniform(75, "sc", (cin,), 0.5, 1.5))
+    sh = torch.from_numpy(synth.uniform(76, "sh", (cin,), -0.5, 0.5))
+    a = F.relu(x.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    yt = F.conv2d(a.double(), w.detach().double())
+    ytg = ops.conv2d_fwd(g(x.detach()), g(w.detach()), 1, 0, g(sc), g(sh), True)
+    assert rel_err(ytg, yt) < 2e-5
+    try:      # same answers as the generic gather path
+        ops.PW = False
+        assert rel_err(ops.conv2d_fwd(g(x.detach()), g(w.detach()), 1, 0, g(sc), g(sh), True), ytg.cpu()) < 2e-5
+    finally:
+        ops.PW = True
+
+
 def test_conv_bias_and_edge_batches(ops):
     for B in (1, 5):
         x = t(10, "x", (B, 20, 9, 9))
