@@ -48,6 +48,13 @@ int scat_conv2d_dgrad(const float* dy, const float* wt, float* dx, int B, int Ci
 int64_t scat_conv2d_dgrad_s2_ws(int Cin, int Cout, int KH, int KW);
 int scat_conv2d_dgrad_s2(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W, int Cout, int KH,
                          int KW, int pad, int accumulate, void* ws, int64_t ws_bytes, void* stream);
+/* How the contraction kernels that support it form fp32 products (scat_conv3x3_s1 today):
+ *   0  v_mfma_f32_32x32x2_f32 — the fp32 matrix instruction (64 FLOP/clk/SIMD);
+ *   1  each fp32 operand split into three bf16 terms (round-to-nearest), six v_mfma_f32_32x32x16_bf16 products
+ *      per fp32 product (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi), fp32 accumulation: the dropped terms are
+ *      <= 2^-25 of the product, below one fp32 rounding.  Default; SCAT_MATH=f32 selects 0 at load time. */
+int scat_get_math_mode(void);
+int scat_set_math_mode(int mode);
 /* 3x3 / stride 1 / pad 1 with an LDS-resident halo (every input element is fetched once per tile instead of
  * once per tap): transposed = 0 -> dst[B,Cout,H,W] = conv(relu(src*scale+shift), w), src[B,Cin,H,W];
  * transposed = 1 -> dst[B,Cin,H,W] (+)= data gradient from src = dy[B,Cout,H,W].  w is the forward weight

@@ -603,5 +603,8 @@ static inline void launch_gemm(const typename LA::Desc& da, const typename LB::D
 }
 
 int tuning();   // SCAT_TUNE environment knob for kernel-variant experiments (0 = shipped default)
+// 0: products on the fp32 MFMA (v_mfma_f32_32x32x2_f32).  1: fp32 operands split into three bf16 terms, six bf16
+// MFMA products per fp32 product, fp32 accumulation (see conv3x3.hip).  SCAT_MATH=f32|bf16x3, scat_set_math_mode().
+int math_mode();
 
 }  // namespace scat

@@ -27,6 +27,15 @@ void set_kernel_label(const char* fmt, ...) {
     va_end(ap);
 }
 
+static int g_math_mode = -1;
+int math_mode() {
+    if (g_math_mode < 0) {
+        const char* e = getenv("SCAT_MATH");
+        g_math_mode = (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : 1;
+    }
+    return g_math_mode;
+}
+
 int tuning() {
     static int v = [] { const char* e = getenv("SCAT_TUNE"); return e ? atoi(e) : 0; }();
     return v;
@@ -382,6 +391,14 @@ using namespace scat;
 extern "C" int scat_version(void) { return 100; }
 extern "C" const char* scat_last_error(void) { return g_err; }
 extern "C" const char* scat_last_kernel(void) { return g_label; }
+
+extern "C" int scat_get_math_mode(void) { return scat::math_mode(); }
+extern "C" int scat_set_math_mode(int mode) {
+    SCAT_REQUIRE(mode == 0 || mode == 1, SCAT_E_ARG, "scat_set_math_mode: 0 (fp32 MFMA) or 1 (bf16x3 split)");
+    scat::math_mode();
+    scat::g_math_mode = mode;
+    return SCAT_OK;
+}
 
 extern "C" int scat_check_device(void) {
     int dev = 0;

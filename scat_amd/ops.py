@@ -58,6 +58,18 @@ def workspace(nbytes: int, device, slot: str = "default") -> torch.Tensor:
     return buf
 
 
+def set_math_mode(mode: int) -> int:
+    """0: fp32 MFMA products; 1: fp32 operands as three bf16 terms, six bf16 MFMA products, fp32 accumulate
+    (include/scat_hip.h).  Returns the previous mode."""
+    old = lib().scat_get_math_mode()
+    lib().scat_set_math_mode(int(mode))
+    return old
+
+
+def get_math_mode() -> int:
+    return lib().scat_get_math_mode()
+
+
 # ---------------------------------------------------------------- convolution
 
 def conv_out_hw(H, W, k, stride, pad):

@@ -22,6 +22,14 @@ def g(x):
     return x.to(DEV).contiguous()
 
 
+@pytest.fixture
+def math_mode(ops):
+    """set the product mode for one test (0 fp32 MFMA, 1 bf16x3 split) and restore the default afterwards"""
+    saved = ops.get_math_mode()
+    yield ops.set_math_mode
+    ops.set_math_mode(saved)
+
+
 @pytest.fixture(scope="module")
 def ops():
     from scat_amd import ops as o
@@ -102,21 +110,24 @@ def test_dgrad_s2_odd_sizes(ops, H, W):
 
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 20, 72, 9, 13), (1, 16, 200, 5, 63), (3, 36, 64, 7, 7),
                                              (2, 64, 132, 30, 4), (5, 128, 128, 14, 14)])
-def test_conv3x3_halo(ops, B, cin, cout, H, W):
+@pytest.mark.parametrize("math", [0, 1])
+def test_conv3x3_halo(ops, math_mode, math, B, cin, cout, H, W):
     """3x3/s1/p1 LDS-halo kernel: ragged channel counts (C % 16 != 0, Cout % 64 != 0), tiles that straddle
     images, rows shorter than the pixel vector, the widest supported row; forward (+fused input transform)
     and data gradient (+accumulate) against fp64 torch and against the generic gather kernel."""
     assert ops.HALO
+    math_mode(math)
+    label = "conv3x3_split" if math else "conv3x3_halo"
     x = t(60, "x", (B, cin, H, W)).requires_grad_(True)
     w = t(61, "w", (cout, cin, 3, 3), std=(2.0 / (cin * 9)) ** 0.5).requires_grad_(True)
     y = F.conv2d(x.double(), w.double(), padding=1)
     dy = t(62, "dy", tuple(y.shape))
     (dx_ref,) = torch.autograd.grad(y, x, dy.double())
     yg = ops.conv2d_fwd(g(x.detach()), g(w.detach()), 1, 1)
-    assert ops.lib().scat_last_kernel().decode().startswith("conv3x3_halo")
+    assert ops.lib().scat_last_kernel().decode().startswith(label)
     assert rel_err(yg, y) < 2e-5
     dxg = ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 1, 1)
-    assert ops.lib().scat_last_kernel().decode().startswith("conv3x3_halo")
+    assert ops.lib().scat_last_kernel().decode().startswith(label)
     assert rel_err(dxg, dx_ref) < 2e-5
     base = g(t(63, "acc", tuple(x.shape)))
     dxa = ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 1, 1, out=base.clone(), accumulate=True)
@@ -168,6 +179,27 @@ def test_conv1x1_pointwise(ops, monkeypatch, B, cin, cout, H, W):
         assert rel_err(ops.conv2d_fwd(g(x.detach()), g(w.detach()), 1, 0, g(sc), g(sh), True), ytg.cpu()) < 2e-5
     finally:
         ops.PW = True
+
+
+def test_split_products_are_as_accurate_as_fp32(ops, math_mode):
+    """The bf16x3 split (six bf16 MFMA terms per product) must not be a precision downgrade: against an fp64
+    reference its error is within a small factor of the fp32-MFMA kernel's own rounding error, on well-scaled
+    data, on data with a 2^20 dynamic range inside every dot product, and far inside the 2e-5 gate."""
+    B, cin, cout, H = 4, 256, 128, 14
+    for name, spread in (("unit", 0.0), ("wide", 20.0)):
+        x = t(90, "x" + name, (B, cin, H, H))
+        w = t(91, "w" + name, (cout, cin, 3, 3), std=(2.0 / (cin * 9)) ** 0.5)
+        if spread:
+            x = x * torch.exp2(torch.from_numpy(synth.uniform(92, "e", tuple(x.shape), -spread / 2, spread / 2)))
+        y = F.conv2d(x.double(), w.double(), padding=1)
+        errs = {}
+        for mode in (0, 1):
+            math_mode(mode)
+            yg = ops.conv2d_fwd(g(x), g(w), 1, 1).cpu().double()
+            errs[mode] = ((yg - y).abs().max() / y.abs().max()).item(), ((yg - y).norm() / y.norm()).item()
+        assert errs[1][0] < 2e-5 and errs[0][0] < 2e-5, errs                  # the op-level gate, both modes
+        assert errs[1][1] < 1.5 * errs[0][1] + 1e-8, errs                     # split is no less accurate than fp32 MFMA
+        assert errs[1][0] < 1.5 * errs[0][0] + 1e-8, errs
 
 
 def test_conv_bias_and_edge_batches(ops):
