@@ -200,6 +200,200 @@ __global__ __launch_bounds__(NT, (BM * BN >= 128 * 128 ? 2 : 3)) void conv1x1_ke
     store_tile<MI, NI, BM, BN, 2, 2>(acc, dc, d.M, d.npix, i0, j0, 0);
 }
 
+// ---------------------------------------------------------------- split-operand variant (see conv3x3.hip)
+//
+// fp32 products as six bf16 MFMA terms of three-way split operands, fp32 accumulation.  The activations are split
+// once per element on the way into LDS ([plane][k-octet][pixel][8 bf16], one ds_read_b128 per plane and
+// fragment); the weights are loaded as fp32 straight into registers (lane (row, h): k = 8h..8h+7, 32 bytes) and
+// split there, in the shadow of the previous chunk's MFMAs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {   // round-to-nearest-even, element 0 in the low half
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2_t));
+}
+__device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = pk_bf16(a, b);
+    a -= __uint_as_float(hi << 16);
+    b -= __uint_as_float(hi & 0xffff0000u);
+    mid = pk_bf16(a, b);
+    a -= __uint_as_float(mid << 16);
+    b -= __uint_as_float(mid & 0xffff0000u);
+    lo = pk_bf16(a, b);
+}
+
+template <int WM, int BN, bool TF>
+__global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(PwDesc d, OutDesc dc) {
+    constexpr int BM = 32 * WM, WN = 4 / WM, NI = BN / (32 * WN);
+    constexpr int NIT = 4 * BN / NT;                  // k-octets staged per thread per 32-channel stage
+    static_assert(NIT >= 1, "tile too small");
+    extern __shared__ __align__(16) float lds[];      // B[2][3 planes][4 k-octets][BN] x 16 bytes
+    auto Bs = [&](int buf) -> u32x4* { return (u32x4*)lds + buf * (12 * BN); };
+
+    const int mt = (d.M + BM - 1) / BM, nt = (d.npix + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int i0 = (tile % mt) * BM, j0 = (tile / mt) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nstage = (d.C + PW_KS - 1) / PW_KS;
+
+    // ---- activation staging: this thread's pixel, k-octets g0 + r*(NT/BN)
+    const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(d.src, d.nsrc);
+    const __amdgpu_buffer_rsrc_t rsrc_sc = make_rsrc(TF ? d.scale : d.src, TF ? d.C : 0);
+    const __amdgpu_buffer_rsrc_t rsrc_sh = make_rsrc(TF ? d.shift : d.src, TF ? d.C : 0);
+    const int pcol = tid % BN, g0 = tid / BN;
+    const int chw4 = d.HW * 4;
+    int boff;
+    bool bok;
+    {
+        const int j = j0 + pcol;
+        bok = j < d.npix;
+        const uint32_t jj = bok ? (uint32_t)j : 0u;
+        const uint32_t n = d.dHW.div(jj);
+        boff = bok ? (int)((n * (uint32_t)d.C * (uint32_t)d.HW + (jj - n * (uint32_t)d.HW)) * 4u) + 8 * g0 * chw4 : OOB;
+    }
+    float bst[NIT][8];
+    u32x4 tsc[TF ? NIT : 1][2], tsh[TF ? NIT : 1][2];
+    auto load_b = [&](int c0) {
+#pragma unroll
+        for (int r = 0; r < NIT; ++r) {
+            const int c = c0 + 8 * (g0 + r * (NT / BN));
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                bst[r][m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    rsrc_b, c + m < d.C ? boff : OOB, (c0 + 8 * r * (NT / BN) + m) * chw4, 0));
+            if constexpr (TF) {
+                const int vo = c < d.C ? c * 4 : OOB;   // C % 16 == 0: an octet is inside or outside as a whole
+                tsc[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, vo, 0, 0);
+                tsc[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, vo, 16, 0);
+                tsh[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, vo, 0, 0);
+                tsh[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, vo, 16, 0);
+            }
+        }
+    };
+    auto store_b = [&](u32x4* dst) {
+#pragma unroll
+        for (int r = 0; r < NIT; ++r) {
+            u32x4 hi, mid, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int m = 2 * q + u;
+                    float t = bst[r][m];
+                    if constexpr (TF) {
+                        t = fmaf(t, __uint_as_float(tsc[r][m >> 2][m & 3]), __uint_as_float(tsh[r][m >> 2][m & 3]));
+                        t = d.relu ? fmaxf(t, 0.f) : t;
+                        t = bok ? t : 0.f;
+                    }
+                    x[u] = t;
+                }
+                uint32_t h, mm, l;
+                split3(x[0], x[1], h, mm, l);
+                hi[q] = h; mid[q] = mm; lo[q] = l;
+            }
+            const int g = g0 + r * (NT / BN);
+            dst[(0 * 4 + g) * BN + pcol] = hi;
+            dst[(1 * 4 + g) * BN + pcol] = mid;
+            dst[(2 * 4 + g) * BN + pcol] = lo;
+        }
+    };
+
+    // ---- weights: fp32 rows straight from global memory, split in registers
+    const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(d.w, d.nw);
+    const int row = i0 + wm * 32 + l31;
+    const int aoff = row < d.M ? (row * d.C + lh * 8) * 4 : OOB;
+    auto load_a = [&](u32x4 (&raw)[2], int c) {
+        const int vo = c < d.C ? aoff : OOB;
+        raw[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, c * 4, 0);
+        raw[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo + 16, c * 4, 0);
+    };
+    auto split_a = [&](u32x4 (&dst)[3], const u32x4 (&raw)[2]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t h, mm, l;
+            split3(__uint_as_float(raw[q >> 1][(2 * q) & 3]), __uint_as_float(raw[q >> 1][(2 * q + 1) & 3]), h, mm, l);
+            dst[0][q] = h; dst[1][q] = mm; dst[2][q] = l;
+        }
+    };
+
+    f32x16 acc[1][NI];
+#pragma unroll
+    for (int b = 0; b < NI; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
+
+    const int b_frag = lh * BN + wn * (BN / WN) + l31;          // u32x4 index inside (plane 0, octet pair 0)
+    auto read_b = [&](u32x4 (&dst)[3], const u32x4* buf, int t, int b) {
+        const u32x4* p = buf + 2 * t * BN + b_frag + b * 32;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dst[q] = p[q * 4 * BN];
+    };
+
+    u32x4 araw[2];
+    u32x4 areg[2][3];
+    u32x4 bfr[2][3];
+
+    load_b(0);
+    load_a(araw, 0);
+    store_b(Bs(0));
+    split_a(areg[0], araw);
+    load_a(araw, 16);
+    __syncthreads();
+    read_b(bfr[0], Bs(0), 0, 0);
+
+    for (int s = 0; s < nstage; ++s) {
+        const int c0 = s * PW_KS;
+        const u32x4* bcur = Bs(s & 1);
+        u32x4* bnext = Bs((s + 1) & 1);
+        load_b(c0 + PW_KS);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            // araw holds the fp32 weights of the NEXT sub-chunk (loaded one sub-chunk ago)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) {
+                const int fcur = (t * NI + b) & 1, fnxt = fcur ^ 1;
+                if (b + 1 < NI) read_b(bfr[fnxt], bcur, t, b + 1);
+                else if (t == 0) read_b(bfr[fnxt], bcur, 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (b == 0) {                           // next sub-chunk's operands: split now, refill the raw buffer
+                    split_a(areg[t ^ 1], araw);
+                    load_a(araw, c0 + 16 * t + 32);
+                }
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[fcur][0]);
+                const bf16x8 bm_ = __builtin_bit_cast(bf16x8, bfr[fcur][1]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, bfr[fcur][2]);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, areg[t][0]);
+                const bf16x8 am = __builtin_bit_cast(bf16x8, areg[t][1]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, areg[t][2]);
+                f32x16 c = acc[0][b];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);   // small terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm_, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm_, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                acc[0][b] = c;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        store_b(bnext);
+        __syncthreads();
+        read_b(bfr[0], bnext, 0, 0);
+    }
+    store_tile<1, NI, BM, BN, WM, WN>(acc, dc, d.M, d.npix, i0, j0, 0);
+}
+
+template <int WM, int BN, bool TF>
+static void launch_pw_split(const PwDesc& d, const OutDesc& dc, hipStream_t st) {
+    constexpr int BM = 32 * WM;
+    const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, BN);
+    constexpr size_t lds_bytes = (size_t)2 * 12 * BN * 16;
+    hipLaunchKernelGGL((conv1x1_split_kernel<WM, BN, TF>), dim3(mt * nt), dim3(NT), lds_bytes, st, d, dc);
+}
+
 template <int BM, int BN, bool V4, bool TF>
 static void launch_pw(const PwDesc& d, const OutDesc& dc, hipStream_t st) {
     const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, BN);
@@ -230,8 +424,8 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* a, float* dst, int
     SCAT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), SCAT_E_ARG, "scat_conv1x1_s1: scale/shift pair");
     SCAT_REQUIRE(C % 16 == 0, SCAT_E_SHAPE, "scat_conv1x1_s1: channels must be a multiple of 16");
     SCAT_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)src & 15) == 0, SCAT_E_ARG, "scat_conv1x1_s1: 16-B alignment");
-    SCAT_REQUIRE(!in_scale || (((uintptr_t)in_scale & 7) == 0 && ((uintptr_t)in_shift & 7) == 0), SCAT_E_ARG,
-                 "scat_conv1x1_s1: scale/shift must be 8-B aligned");
+    SCAT_REQUIRE(!in_scale || (((uintptr_t)in_scale & 15) == 0 && ((uintptr_t)in_shift & 15) == 0), SCAT_E_ARG,
+                 "scat_conv1x1_s1: scale/shift must be 16-B aligned");
     SCAT_REQUIRE(fits_i32((int64_t)B * C * HW * 4) && fits_i32((int64_t)B * M * HW * 4) && fits_i32((int64_t)M * C * 4),
                  SCAT_E_SHAPE, "scat_conv1x1_s1: tensor exceeds 32-bit byte offsets");
     hipStream_t st = (hipStream_t)stream;
@@ -246,6 +440,21 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* a, float* dst, int
     int cfg = (M > 64 && tiles(128, 128) >= 1024) ? 0 : 2;   // measured: 64x128 never wins at batch 96
     if (tuning() >= 1 && tuning() <= 3) cfg = tuning() - 1;
     static const char* const names[] = {"128x128", "64x128", "64x64"};
+    if (math_mode() == 1) {
+        if (!(tuning() >= 1 && tuning() <= 3)) cfg = M > 64 ? 0 : 1;   // measured at batch 96: 64x64 never wins
+        set_kernel_label("conv1x1_split_%sx32%s", names[cfg], in_scale ? "_tf" : "");
+        if (in_scale) {
+            if (cfg == 0) launch_pw_split<4, 128, true>(d, dc, st);
+            else if (cfg == 1) launch_pw_split<2, 128, true>(d, dc, st);
+            else launch_pw_split<2, 64, true>(d, dc, st);
+        } else {
+            if (cfg == 0) launch_pw_split<4, 128, false>(d, dc, st);
+            else if (cfg == 1) launch_pw_split<2, 128, false>(d, dc, st);
+            else launch_pw_split<2, 64, false>(d, dc, st);
+        }
+        SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
+        return SCAT_OK;
+    }
     const bool v4 = HW % 4 == 0;
     set_kernel_label("conv1x1_pw_%sx32%s%s", names[cfg], v4 ? "_b4" : "", in_scale ? "_tf" : "");
     if (v4) {

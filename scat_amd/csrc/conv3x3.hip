@@ -539,7 +539,11 @@ extern "C" int scat_conv3x3_s1(const float* src, const float* w, float* dst, int
     const int bm = cfg == 0 ? 128 : 64, bn = cfg == 2 ? 64 : 128;
     d.RS = bn + 2 * (W + 1);
     if (split) {
-        set_kernel_label("conv3x3_split_%dx%dx16%s%s", bm, bn, transposed ? "_dgrad" : "", in_scale ? "_tf" : "");
+        if (!(tuning() >= 1 && tuning() <= 3)) {         // measured at batch 96: 64x128 unless the grid gets thin
+            cfg = tiles(64, 128) >= 512 ? 1 : 2;
+            d.RS = (cfg == 2 ? 64 : 128) + 2 * (W + 1);
+        }
+        set_kernel_label("conv3x3_split_%dx%dx16%s%s", cfg == 0 ? 128 : 64, cfg == 2 ? 64 : 128, transposed ? "_dgrad" : "", in_scale ? "_tf" : "");
         if (in_scale) {
             if (cfg == 0) launch_split<4, 128, true>(d, dc, st);
             else if (cfg == 1) launch_split<2, 128, true>(d, dc, st);

@@ -90,7 +90,9 @@ PW = os.environ.get("SCAT_PW", "1") != "0"       # 1x1/s1 through the weights-in
 def _pw_ok(KH, KW, stride, pad, csrc, *ts):
     # measured (tools/conv_bench.py, batch 96): ahead of the generic engine from 512 contraction channels up,
     # behind it on the short, store-bound contractions of layer1/layer2 (PW_MIN_C=0 forces it, for tests)
-    return (PW and KH == 1 and KW == 1 and stride == 1 and pad == 0 and csrc % 16 == 0 and csrc >= PW_MIN_C
+    # (with split-operand products it is ahead everywhere)
+    return (PW and KH == 1 and KW == 1 and stride == 1 and pad == 0 and csrc % 16 == 0
+            and (csrc >= PW_MIN_C or lib().scat_get_math_mode() == 1)
             and all(t is None or t.data_ptr() % 16 == 0 for t in ts))
 
 

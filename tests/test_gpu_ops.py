@@ -147,12 +147,15 @@ def test_conv3x3_halo(ops, math_mode, math, B, cin, cout, H, W):
 
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 48, 80, 9, 13), (1, 16, 208, 5, 64), (3, 32, 64, 7, 7),
                                              (2, 64, 144, 30, 4), (5, 256, 128, 14, 14)])
-def test_conv1x1_pointwise(ops, monkeypatch, B, cin, cout, H, W):
+@pytest.mark.parametrize("math", [0, 1])
+def test_conv1x1_pointwise(ops, monkeypatch, math_mode, math, B, cin, cout, H, W):
     """1x1/s1 weights-in-registers kernel: vector and scalar pixel staging (HW % 4), channel counts that are
     odd multiples of 16, ragged row/pixel tiles; forward (+bias, +fused input transform) and data gradient
     (+accumulate) against fp64 torch and against the generic gather kernel."""
     assert ops.PW
     monkeypatch.setattr(ops, "PW_MIN_C", 0)
+    math_mode(math)
+    label = "conv1x1_split" if math else "conv1x1_pw"
     x = t(70, "x", (B, cin, H, W)).requires_grad_(True)
     w = t(71, "w", (cout, cin, 1, 1), std=(2.0 / cin) ** 0.5).requires_grad_(True)
     bias = t(72, "b", (cout,))
@@ -160,10 +163,10 @@ def test_conv1x1_pointwise(ops, monkeypatch, B, cin, cout, H, W):
     dy = t(73, "dy", tuple(y.shape))
     (dx_ref,) = torch.autograd.grad(y, x, dy.double())
     yg = ops.conv2d_fwd(g(x.detach()), g(w.detach()), 1, 0, bias=g(bias))
-    assert ops.lib().scat_last_kernel().decode().startswith("conv1x1_pw")
+    assert ops.lib().scat_last_kernel().decode().startswith(label)
     assert rel_err(yg, y) < 2e-5
     dxg = ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 1, 0)
-    assert ops.lib().scat_last_kernel().decode().startswith("conv1x1_pw")
+    assert ops.lib().scat_last_kernel().decode().startswith(label)
     assert rel_err(dxg, dx_ref) < 2e-5
     base = g(t(74, "acc", tuple(x.shape)))
     dxa = ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 1, 0, out=base.clone(), accumulate=True)
