@@ -14,6 +14,7 @@
 // Replaces nn.Conv2d(k=1) and its input gradient as called at models/resnet.py:65-67,70-72,84-92 of the
 // reference (conv1/conv3 of every Bottleneck) and the 1x1 reductions of models/hand_net.py, fp32.
 #include "conv_common.h"
+#include "split.h"
 
 namespace scat {
 
@@ -30,8 +31,6 @@ struct PwDesc {
 
 constexpr int PW_KS = 32;     // channels per LDS stage (two 16-channel sub-chunks)
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int BM, int BN, bool V4, bool TF>
 __global__ __launch_bounds__(NT, (BM * BN >= 128 * 128 ? 2 : 3)) void conv1x1_kernel(PwDesc d, OutDesc dc) {
@@ -206,22 +205,6 @@ __global__ __launch_bounds__(NT, (BM * BN >= 128 * 128 ? 2 : 3)) void conv1x1_ke
 // once per element on the way into LDS ([plane][k-octet][pixel][8 bf16], one ds_read_b128 per plane and
 // fragment); the weights are loaded as fp32 straight into registers (lane (row, h): k = 8h..8h+7, 32 bytes) and
 // split there, in the shadow of the previous chunk's MFMAs.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {   // round-to-nearest-even, element 0 in the low half
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2_t));
-}
-__device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    hi = pk_bf16(a, b);
-    a -= __uint_as_float(hi << 16);
-    b -= __uint_as_float(hi & 0xffff0000u);
-    mid = pk_bf16(a, b);
-    a -= __uint_as_float(mid << 16);
-    b -= __uint_as_float(mid & 0xffff0000u);
-    lo = pk_bf16(a, b);
-}
-
 template <int WM, int BN, bool TF>
 __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(PwDesc d, OutDesc dc) {
     constexpr int BM = 32 * WM, WN = 4 / WM, NI = BN / (32 * WN);

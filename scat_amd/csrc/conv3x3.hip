@@ -17,6 +17,7 @@
 // Replaces nn.Conv2d(k=3, s=1, p=1) and its input gradient as called at models/resnet.py:68-69,86-88 of
 // the reference (the conv2 of every Bottleneck), fp32.
 #include "conv_common.h"
+#include "split.h"
 
 namespace scat {
 
@@ -36,7 +37,6 @@ struct HaloDesc {
 constexpr int HB_K = 16;      // source channels per chunk
 constexpr int HB_TLOAD = 6;   // tap at which the next chunk's halo loads are issued (written to LDS after tap 8)
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int BM, int HB_N, bool TF>
 __global__ __launch_bounds__(NT, (BM * HB_N >= 128 * 128 ? 2 : 3)) void conv3x3_halo_kernel(HaloDesc d, OutDesc dc) {
@@ -244,23 +244,6 @@ __global__ void wt3x3_kernel(const float* __restrict__ w, float* __restrict__ wt
 //   A: planes of the re-laid weights wt[tap][chunk][plane][row][16 bf16], one 16-B load per plane;
 //   B: LDS halo rows [plane][h][pixel][8 bf16]: one ds_read_b128 per plane at the tap-shifted pixel.
 // The split of the activations happens once per element on the way into LDS.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {   // round-to-nearest-even, element 0 in the low half
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
-}
-__device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    hi = pk_bf16(a, b);
-    a -= __uint_as_float(hi << 16);
-    b -= __uint_as_float(hi & 0xffff0000u);
-    mid = pk_bf16(a, b);
-    a -= __uint_as_float(mid << 16);
-    b -= __uint_as_float(mid & 0xffff0000u);
-    lo = pk_bf16(a, b);
-}
-
 // WM waves along the output rows (32 rows each), 4/WM along the pixels; BM = 32*WM.
 template <int WM, int HB_N, bool TF>
 __global__ __launch_bounds__(NT, 2) void conv3x3_split_kernel(HaloDesc d, OutDesc dc) {

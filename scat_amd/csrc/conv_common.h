@@ -20,4 +20,14 @@ static inline int check_geom(const char* who, int B, int Cin, int H, int W, int 
     return SCAT_OK;
 }
 
+// split-operand weight gradient (conv_wgrad_split.hip): 1x1/pad 0 and 3x3/pad 1, stride 1
+struct WgSplitPlan {
+    int M, N, mi, ni, stages, spz, splits;
+};
+WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW);
+void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, float* out, int B, int Cin, int H, int W,
+                        int Cout, int KK, const float* in_scale, const float* in_shift, int in_relu, hipStream_t st);
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int splits,
+                                     int accumulate);
+
 }  // namespace scat

@@ -71,6 +71,13 @@ static void wgrad_gemm(const WgradPlan& p, const GatherDesc& da, const GatherDes
     wgrad_gemm_tf<KH, KW, AV4, BV4, false>(p, da, db, dc, st);
 }
 
+// measured at batch 96: the split kernel wins except where the output is tiny and the contraction huge
+// (layer1's 64x64 / 64x256 1x1 convs: staging-bound 64-row tiles), which stay on the fp32 engine
+static bool wgrad_split_ok(int KH, int stride, int pad, int Cout, int Cin) {
+    return stride == 1 && ((KH == 1 && pad == 0) || (KH == 3 && pad == 1)) &&
+           (int64_t)Cout * Cin * KH * KH > 64 * 256;
+}
+
 }  // namespace scat
 
 using namespace scat;
@@ -79,7 +86,13 @@ extern "C" int64_t scat_conv2d_wgrad_ws(int B, int Cin, int H, int W, int Cout, 
     int OH, OW;
     if (check_geom("scat_conv2d_wgrad_ws", B, Cin, H, W, Cout, KH, KW, stride, pad, &OH, &OW)) return -1;
     WgradPlan p = wgrad_plan(B, Cin, Cout, KH * KW, OH, OW);
-    return p.splits > 1 ? (int64_t)p.splits * p.M * p.N * sizeof(float) : 0;
+    int64_t need = p.splits > 1 ? (int64_t)p.splits * p.M * p.N * sizeof(float) : 0;
+    if (wgrad_split_ok(KH, stride, pad, Cout, Cin)) {            // the math mode may change between this query and the call
+        WgSplitPlan q = wgrad_split_plan(B, Cin, Cout, KH * KW, H * W);
+        int64_t n2 = q.splits > 1 ? (int64_t)q.splits * q.M * q.N * sizeof(float) : 0;
+        if (n2 > need) need = n2;
+    }
+    return need;
 }
 
 extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout,
@@ -91,6 +104,23 @@ extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int
     SCAT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), SCAT_E_ARG, "scat_conv2d_wgrad: scale/shift pair");
     SCAT_REQUIRE(!(in_scale && KH == 7), SCAT_E_SHAPE, "scat_conv2d_wgrad: fused input transform not built for 7x7");
     if (!in_scale) in_relu = 0;
+    if (math_mode() == 1 && wgrad_split_ok(KH, stride, pad, Cout, Cin)) {
+        const WgSplitPlan q = wgrad_split_plan(B, Cin, Cout, KH * KW, H * W);
+        const int64_t need2 = q.splits > 1 ? (int64_t)q.splits * q.M * q.N * sizeof(float) : 0;
+        SCAT_REQUIRE(ws_bytes >= need2 && (need2 == 0 || ws), SCAT_E_WORKSPACE,
+                     "scat_conv2d_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need2);
+        hipStream_t st2 = (hipStream_t)stream;
+        wgrad_split_launch(q, dy, x, q.splits > 1 ? (float*)ws : dw, B, Cin, H, W, Cout, KH * KW, in_scale, in_shift,
+                           in_relu, st2);
+        SCAT_LAUNCH_CHECK("scat_conv2d_wgrad");
+        if (q.splits > 1) {
+            int64_t n = (int64_t)q.M * q.N;
+            int blocks = (int)((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(64), 0, st2, (const float*)ws, dw, n, q.splits, 0);
+            SCAT_LAUNCH_CHECK("scat_conv2d_wgrad(reduce)");
+        }
+        return SCAT_OK;
+    }
     WgradPlan p = wgrad_plan(B, Cin, Cout, KH * KW, OH, OW);
     int64_t need = p.splits > 1 ? (int64_t)p.splits * p.M * p.N * sizeof(float) : 0;
     SCAT_REQUIRE(ws_bytes >= need && (need == 0 || ws), SCAT_E_WORKSPACE,

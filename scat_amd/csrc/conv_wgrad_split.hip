@@ -1,0 +1,268 @@
+// Convolution weight gradient (1x1 and 3x3/pad 1, stride 1) with split-operand products (split.h):
+//   dW[co][(ci,tap)] = sum over pixels  dy[n][co][r] * f(x[n][ci][r + shift(tap)]),   f = relu(x*scale+shift)
+// an "NT" contraction whose two operands are both contiguous along the contraction index (pixels):
+//  * a staging thread owns one (row, pixel octet): 8 consecutive pixels of a dy row / of an x row shifted by the
+//    tap = 32 contiguous bytes = two 16-B loads; it applies the fused transform and the per-pixel padding mask,
+//    splits the 8 values into the three bf16 fragments and writes three ds_write_b128 — the LDS image
+//    [plane][octet][row][8 bf16] is exactly the MFMA operand layout (lane (row, h) <- octet h).
+//  * images are walked in octets (ceil(HW/8) per image, the ragged last one masked), so an octet never straddles
+//    two images and 7x7 / 14x14 planes need no special path.
+//  * 16 pixels per stage, LDS double-buffered, global loads for the next stage in flight under the MFMAs.
+//  * deterministic split-K over pixel stages into fp32 slabs, reduced in a fixed order (splitk_reduce_kernel).
+// Replaces the autograd weight gradient of nn.Conv2d at models/resnet.py:65-72 (conv1, conv2, conv3, downsample).
+#include "conv_common.h"
+#include "split.h"
+
+namespace scat {
+
+struct WgDesc {
+    const float* dy;      // [B][Cout][HW]
+    const float* x;       // [B][Cin][HW]
+    const float* scale;   // optional fused input transform on x, per Cin
+    const float* shift;
+    int relu;
+    int Cout, Cin, H, W, HW;
+    int NO;               // octets per image = ceil(HW / 8)
+    int U;                // octets in total = B * NO
+    int N;                // columns = Cin * KK
+    int spz;              // stages (2 octets each) per split-K slice
+    FastDiv dNO, dW, dKK;
+    int64_t ndy, nx;
+};
+
+// 8 consecutive floats at byte offset off (OOB: zeros).  Two 16-B loads; a vector that would start before or end
+// after the tensor (first / last rows of the whole tensor only) is fetched as 8 bounds-checked dwords instead,
+// so nothing depends on how the hardware range-checks a partly out-of-range vector.
+__device__ __forceinline__ void load8(__amdgpu_buffer_rsrc_t rs, int off, uint32_t mask, int64_t nfloats,
+                                      float (&v)[8]) {
+    if (off != OOB && (off < 0 || (int64_t)off + 32 > nfloats * 4)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int o = off + 4 * e;
+            const bool ok = ((mask >> e) & 1u) && o >= 0 && (int64_t)o + 4 <= nfloats * 4;
+            v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, ok ? o : OOB, 0, 0));
+        }
+        return;
+    }
+    const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 16, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] = __uint_as_float(t0[q]); v[4 + q] = __uint_as_float(t1[q]); }
+}
+
+template <int KK, int MI, int NI, bool TF>
+__global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc) {
+    constexpr int BM = 64 * MI, BN = 64 * NI;
+    constexpr int OSA = BM + 8, OSB = BN + 8;          // u32x4 per (plane, octet) slab; +128 B keeps the two octets of
+                                                       // a row pair on different banks for the staging writes
+    extern __shared__ __align__(16) float lds[];       // [2 buffers][A: 6 slabs of OSA | B: 6 slabs of OSB] x 16 B
+    auto As = [&](int buf) -> u32x4* { return (u32x4*)lds + buf * 6 * (OSA + OSB); };
+    auto Bs = [&](int buf) -> u32x4* { return (u32x4*)lds + buf * 6 * (OSA + OSB) + 6 * OSA; };
+
+    const int mt = (d.Cout + BM - 1) / BM, nt = (d.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int i0 = (tile % mt) * BM, j0 = (tile / mt) * BN;
+    const int z = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int sbeg = z * d.spz, send = min(sbeg + d.spz, (d.U + 1) >> 1);
+
+    // ---- staging items: (row, octet) = (tid >> 1, tid & 1) of each operand
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(d.dy, d.ndy), rsb = make_rsrc(d.x, d.nx);
+    const int srow = tid >> 1, so = tid & 1;
+    const bool a_item = srow < BM, b_item = srow < BN;
+    const int arow = i0 + srow;
+    const bool a_ok = a_item && arow < d.Cout;
+    const int col = j0 + srow;
+    const bool b_ok = b_item && col < d.N;
+    int ci = 0, kh = 1, kw = 1;
+    if (KK == 9) {
+        const uint32_t c = d.dKK.div((uint32_t)(b_ok ? col : 0));
+        const int tap = (b_ok ? col : 0) - (int)c * 9;
+        ci = (int)c; kh = tap / 3; kw = tap - 3 * kh;
+    } else {
+        ci = b_ok ? col : 0;
+    }
+    const int bshift = (kh - 1) * d.W + (kw - 1);
+    float bsc = 1.f, bsh = 0.f;
+    if (TF && b_ok) { bsc = d.scale[ci]; bsh = d.shift[ci]; }
+
+    // two register sets: the loads of stage s+2 are issued at the top of stage s and written to LDS at the end of
+    // stage s+1, i.e. ~2 x (MI*NI*6) MFMAs of cover for an HBM miss
+    float araw[2][8], braw[2][8];
+    uint32_t amask[2] = {0, 0}, bmask[2] = {0, 0};     // validity of the 8 pixels
+    auto load_stage = [&](int s, auto set_tag) {
+        constexpr int Q = decltype(set_tag)::value;
+        const int u = 2 * s + so;
+        const bool in = s < send && u < d.U;
+        const uint32_t uu = in ? (uint32_t)u : 0u;
+        const uint32_t n = d.dNO.div(uu);
+        const int r0 = 8 * (int)(uu - n * (uint32_t)d.NO);
+        const int cnt = in ? min(8, d.HW - r0) : 0;
+        const uint32_t live = (1u << cnt) - 1u;
+        // A: dy[n][arow][r0 .. r0+7]
+        {
+            const int off = (a_ok && cnt > 0) ? (((int)n * d.Cout + arow) * d.HW + r0) * 4 : OOB;
+            load8(rsa, off, a_ok ? live : 0u, d.ndy, araw[Q]);
+            amask[Q] = a_ok ? live : 0u;
+        }
+        // B: x[n][ci][r0 + shift .. +7], per-pixel padding mask
+        {
+            uint32_t m = live;
+            if (KK == 9) {
+                const int y0 = (int)d.dW.div((uint32_t)r0), x0 = r0 - y0 * d.W;
+                uint32_t v = 0;
+                int y = y0 + kh - 1, x = x0 + kw - 1;      // source row / column of pixel e
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    // x runs past the row end after the wrap: the source column restarts at kw-1
+                    const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
+                    v |= (ok ? 1u : 0u) << e;
+                    ++x;
+                    if (x == d.W + kw - 1) { x = kw - 1; ++y; }
+                }
+                m &= v;
+            }
+            m = b_ok ? m : 0u;
+            const int off = m ? (((int)n * d.Cin + ci) * d.HW + r0 + bshift) * 4 : OOB;
+            load8(rsb, off, m, d.nx, braw[Q]);
+            bmask[Q] = m;
+        }
+    };
+    auto store_stage = [&](int buf, auto set_tag) {
+        constexpr int Q = decltype(set_tag)::value;
+        if (a_item) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = ((amask[Q] >> e) & 1u) ? araw[Q][e] : 0.f;
+            u32x4 hi, mid, lo;
+            split3x8(v, hi, mid, lo);
+            u32x4* p = As(buf) + so * OSA + srow;
+            p[0] = hi; p[2 * OSA] = mid; p[4 * OSA] = lo;
+        }
+        if (b_item) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = braw[Q][e];
+                if constexpr (TF) {
+                    t = fmaf(t, bsc, bsh);
+                    t = d.relu ? fmaxf(t, 0.f) : t;
+                }
+                v[e] = ((bmask[Q] >> e) & 1u) ? t : 0.f;
+            }
+            u32x4 hi, mid, lo;
+            split3x8(v, hi, mid, lo);
+            u32x4* p = Bs(buf) + so * OSB + srow;
+            p[0] = hi; p[2 * OSB] = mid; p[4 * OSB] = lo;
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int afrag = lh * OSA + wm * (BM / 2) + l31, bfrag = lh * OSB + wn * (BN / 2) + l31;
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    // stage sbeg + t lives in LDS buffer t & 1 and came through register set t & 1
+    auto stage = [&](int s, auto cur_tag) {
+        constexpr int CUR = decltype(cur_tag)::value;
+        load_stage(s + 2, std::integral_constant<int, CUR>{});      // past the end: every lane reads 0
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 af[MI][3], bf[NI][3];
+        const u32x4* pa = As(CUR) + afrag;
+        const u32x4* pb = Bs(CUR) + bfrag;
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[a][p] = pa[p * 2 * OSA + a * 32];
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[b][p] = pb[p * 2 * OSB + b * 32];
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) acc[a][b] = mfma_split(af[a], bf[b], acc[a][b]);
+        __builtin_amdgcn_sched_barrier(0);
+        store_stage(CUR ^ 1, std::integral_constant<int, CUR ^ 1>{});   // stage s+1, loaded one stage ago
+        __syncthreads();
+    };
+    if (sbeg < send) {
+        load_stage(sbeg, S0{});
+        load_stage(sbeg + 1, S1{});
+        store_stage(0, S0{});
+    }
+    __syncthreads();
+    for (int s = sbeg; s < send; s += 2) {
+        stage(s, S0{});
+        if (s + 1 < send) stage(s + 1, S1{});
+    }
+    store_tile<MI, NI, BM, BN, 2, 2>(acc, dc, d.Cout, d.N, i0, j0, z);
+}
+
+template <int KK, int MI, int NI, bool TF>
+static void launch_wg(const WgDesc& d, const OutDesc& dc, int splits, hipStream_t st) {
+    constexpr int BM = 64 * MI, BN = 64 * NI;
+    const int mt = cdiv(d.Cout, BM), nt = cdiv(d.N, BN);
+    constexpr size_t lds_bytes = (size_t)2 * 6 * (BM + 8 + BN + 8) * 16;
+    hipLaunchKernelGGL((wgrad_split_kernel<KK, MI, NI, TF>), dim3(mt * nt, 1, splits), dim3(NT), lds_bytes, st, d, dc);
+}
+
+template <int KK, bool TF>
+static void launch_wg_tile(int mi, int ni, const WgDesc& d, const OutDesc& dc, int splits, hipStream_t st) {
+    if (mi == 2 && ni == 2) launch_wg<KK, 2, 2, TF>(d, dc, splits, st);
+    else if (mi == 2) launch_wg<KK, 2, 1, TF>(d, dc, splits, st);
+    else if (ni == 2) launch_wg<KK, 1, 2, TF>(d, dc, splits, st);
+    else launch_wg<KK, 1, 1, TF>(d, dc, splits, st);
+}
+
+WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW) {
+    WgSplitPlan p;
+    p.M = Cout;
+    p.N = Cin * KK;
+    p.mi = Cout > 64 ? 2 : 1;
+    p.ni = p.N > 64 ? 2 : 1;
+    const int NO = (HW + 7) / 8;
+    p.stages = (B * NO + 1) / 2;
+    const int tiles = cdiv(p.M, 64 * p.mi) * cdiv(p.N, 64 * p.ni);
+    int s = cdiv(1536, tiles);                        // ~6 workgroups per CU over the whole grid
+    const int smax = p.stages / 24 > 0 ? p.stages / 24 : 1;   // >= 24 stages (384 pixels) per slice
+    if (s > smax) s = smax;
+    if (s > 512) s = 512;
+    if (s < 1) s = 1;
+    p.spz = cdiv(p.stages, s);
+    p.splits = cdiv(p.stages, p.spz);
+    return p;
+}
+
+void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, float* out, int B, int Cin, int H, int W,
+                        int Cout, int KK, const float* in_scale, const float* in_shift, int in_relu, hipStream_t st) {
+    WgDesc d{};
+    d.dy = dy; d.x = x; d.scale = in_scale; d.shift = in_shift; d.relu = in_scale ? in_relu : 0;
+    d.Cout = Cout; d.Cin = Cin; d.H = H; d.W = W; d.HW = H * W;
+    d.NO = (d.HW + 7) / 8; d.U = B * d.NO; d.N = p.N; d.spz = p.spz;
+    d.dNO = FastDiv::make(d.NO); d.dW = FastDiv::make(W); d.dKK = FastDiv::make(KK);
+    d.ndy = (int64_t)B * Cout * d.HW; d.nx = (int64_t)B * Cin * d.HW;
+    OutDesc dc{};
+    dc.p = out; dc.mode = 0; dc.si = p.N; dc.sj = 1; dc.sz = (int64_t)p.M * p.N; dc.I = p.M; dc.J = p.N;
+    dc.n = (int64_t)p.M * p.N;
+    set_kernel_label("wgrad%s_split_%dx%dx16%s_split%d", KK == 9 ? "3x3" : "1x1", 64 * p.mi, 64 * p.ni,
+                     in_scale ? "_tf" : "", p.splits);
+    if (KK == 9) {
+        if (in_scale) launch_wg_tile<9, true>(p.mi, p.ni, d, dc, p.splits, st);
+        else launch_wg_tile<9, false>(p.mi, p.ni, d, dc, p.splits, st);
+    } else {
+        if (in_scale) launch_wg_tile<1, true>(p.mi, p.ni, d, dc, p.splits, st);
+        else launch_wg_tile<1, false>(p.mi, p.ni, d, dc, p.splits, st);
+    }
+}
+
+}  // namespace scat

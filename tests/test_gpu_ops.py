@@ -205,6 +205,29 @@ def test_split_products_are_as_accurate_as_fp32(ops, math_mode):
         assert errs[1][0] < 1.5 * errs[0][0] + 1e-8, errs
 
 
+@pytest.mark.parametrize("math", [0, 1])
+@pytest.mark.parametrize("B,cin,cout,H,W,k", [(2, 20, 136, 9, 13, 3), (3, 36, 64, 7, 7, 3), (2, 64, 132, 30, 4, 3),
+                                               (5, 128, 128, 14, 14, 3), (2, 144, 136, 9, 13, 1), (3, 160, 112, 7, 7, 1),
+                                               (1, 96, 208, 5, 64, 1), (4, 3, 5, 6, 5, 3)])
+def test_wgrad_stride1(ops, math_mode, math, B, cin, cout, H, W, k):
+    """weight gradient of 1x1/pad 0 and 3x3/pad 1: planes that are not a multiple of 8 pixels (ragged octets), rows
+    shorter than an octet (taps wrap inside a vector, first/last vectors poke outside the tensor), ragged
+    row/column tiles, with and without the fused input transform; both product modes."""
+    math_mode(math)
+    x = t(80, "x", (B, cin, H, W))
+    w_shape = (cout, cin, k, k)
+    dy = t(81, "dy", (B, cout, H, W))
+    sc = torch.from_numpy(synth.uniform(82, "sc", (cin,), 0.5, 1.5))
+    sh = torch.from_numpy(synth.uniform(83, "sh", (cin,), -0.5, 0.5))
+    for tf in (False, True):
+        a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if tf else x
+        ref = torch.nn.grad.conv2d_weight(a.double(), w_shape, dy.double(), padding=k // 2)
+        got = ops.conv2d_wgrad(g(dy), g(x), w_shape, 1, k // 2, *((g(sc), g(sh), True) if tf else ()))
+        # (outputs of <= 64x256 weights stay on the fp32 engine in either mode)
+        assert ("_split_" in ops.lib().scat_last_kernel().decode()) == (bool(math) and cout * cin * k * k > 64 * 256)
+        assert rel_err(got, ref) < 2e-5, tf
+
+
 def test_conv_bias_and_edge_batches(ops):
     for B in (1, 5):
         x = t(10, "x", (B, 20, 9, 9))
