@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 # fp32 work per image of one train step (SURVEY §8d / BASELINE.md §2, torch flop counter on the reference)
 GF_TRAIN_PER_IMG = 24.987
 PEAK_F32_MFMA_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TF = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16, 32 clk)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -115,8 +116,14 @@ def dominant_kernel_roofline(ts, x, lab):
             traffic = json.load(fh).get(name, {}).get("hbm_bytes_per_launch")
     except OSError:
         pass
-    roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic, "kernel": name, "launches_per_step": n,
+    # kernels whose label says "split" form each fp32 product from six bf16 MFMA terms: their
+    # ceiling for ALGORITHMIC fp32 FLOPs is the dense bf16 MFMA peak / 6; the others use the fp32 MFMA
+    split = "_split" in name
+    peak = round(PEAK_BF16_MFMA_TF / 6.0, 1) if split else PEAK_F32_MFMA_TF
+    roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(tf / peak, 4), "traffic": traffic, "kernel": name, "launches_per_step": n,
+            "peak_basis": ("2500 TF dense bf16 MFMA / 6 bf16 terms per fp32 product" if split
+                           else "157.3 TF fp32 MFMA"),
             "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3)}
     return roof, table
 
@@ -196,6 +203,9 @@ def main():
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": "3x224x224 fp32 "
                        "(from 256x256 synthetic uint8, resized before the timed region)",
                        "parallelism": f"dp{world}", "final_loss": final_loss,
+                       "products": ("fp32 operands as 3 bf16 terms, 6 bf16 MFMA terms per product, fp32 accumulate "
+                                    "(error <= 2^-25 per product; DESIGN.md 3.0)" if lib().scat_get_math_mode() == 1
+                                    else "fp32 MFMA"),
                        "whole_step_tflops_per_gpu": round(step_tf, 2)},
             "roofline": roof, "cpu_baseline": cpu,
         }
