@@ -64,12 +64,16 @@ int64_t scat_conv3x3_s1_ws(int Cout, int Cin);
 int scat_conv3x3_s1(const float* src, const float* w, float* dst, int B, int Cin, int H, int W, int Cout,
                     int transposed, const float* in_scale, const float* in_shift, int in_relu, int accumulate,
                     void* ws, int64_t ws_bytes, void* stream);
-/* Pointwise (1x1, stride 1, pad 0) conv: dst[B,M,HW] (+)= a[M,C] . relu(src[B,C,HW]*scale+shift) (+ bias[M]).
+/* Pointwise (1x1, stride 1, pad 0) conv: dst[B,M,HW] (+)= A[M,C] . relu(src[B,C,HW]*scale+shift) (+ bias[M]).
  * Weights go straight from L2 to the MFMA operand registers, activations through LDS 32 channels per barrier.
- * Forward: a = w[Cout,Cin]; data gradient: a = scat_conv2d_wt(w) = [Cin,Cout], src = dy.  Needs C % 16 == 0 and
- * 16-B aligned a/src.  Replaces nn.Conv2d(k=1) at models/resnet.py:65-72 and its autograd. */
-int scat_conv1x1_s1(const float* src, const float* a, float* dst, int B, int C, int HW, int M, const float* bias,
-                    const float* in_scale, const float* in_shift, int in_relu, int accumulate, void* stream);
+ * transposed = 0 (forward): w = [M,C] = the conv weight [Cout,Cin];  transposed = 1 (data gradient): w = [C,M] is
+ * still the forward weight (M = Cin, C = Cout) and src = dy.  ws: scat_conv1x1_s1_ws(M, C) bytes for the re-laid
+ * weights.  Needs C % 16 == 0 and 16-B aligned w/src/ws.  Replaces nn.Conv2d(k=1) at models/resnet.py:65-72 and
+ * its autograd. */
+int64_t scat_conv1x1_s1_ws(int M, int C);
+int scat_conv1x1_s1(const float* src, const float* w, float* dst, int B, int C, int HW, int M, int transposed,
+                    const float* bias, const float* in_scale, const float* in_shift, int in_relu, int accumulate,
+                    void* ws, int64_t ws_bytes, void* stream);
 /* wt[Cin][Cout*KH*KW] = w[Cout][Cin][KH][KW] re-laid for the data-gradient contraction. */
 int scat_conv2d_wt(const float* w, float* wt, int Cout, int Cin, int KH, int KW, void* stream);
 /* dw[Cout,Cin,KH,KW] = sum over pixels dy * relu(x*scale+shift).  Deterministic two-stage

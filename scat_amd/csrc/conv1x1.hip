@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NT, (BM * BN >= 128 * 128 ? 2 : 3)) void conv1x1_ke
 // fragment); the weights are loaded as fp32 straight into registers (lane (row, h): k = 8h..8h+7, 32 bytes) and
 // split there, in the shadow of the previous chunk's MFMAs.
 template <int WM, int BN, bool TF>
-__global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(PwDesc d, OutDesc dc) {
+__global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc dc) {
     constexpr int BM = 32 * WM, WN = 4 / WM, NI = BN / (32 * WN);
     constexpr int NIT = 4 * BN / NT;                  // k-octets staged per thread per 32-channel stage
     static_assert(NIT >= 1, "tile too small");
@@ -223,8 +223,6 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(PwDesc d, OutDesc 
 
     // ---- activation staging: this thread's pixel, k-octets g0 + r*(NT/BN)
     const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(d.src, d.nsrc);
-    const __amdgpu_buffer_rsrc_t rsrc_sc = make_rsrc(TF ? d.scale : d.src, TF ? d.C : 0);
-    const __amdgpu_buffer_rsrc_t rsrc_sh = make_rsrc(TF ? d.shift : d.src, TF ? d.C : 0);
     const int pcol = tid % BN, g0 = tid / BN;
     const int chw4 = d.HW * 4;
     int boff;
@@ -236,26 +234,25 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(PwDesc d, OutDesc 
         const uint32_t n = d.dHW.div(jj);
         boff = bok ? (int)((n * (uint32_t)d.C * (uint32_t)d.HW + (jj - n * (uint32_t)d.HW)) * 4u) + 8 * g0 * chw4 : OOB;
     }
-    float bst[NIT][8];
-    u32x4 tsc[TF ? NIT : 1][2], tsh[TF ? NIT : 1][2];
-    auto load_b = [&](int c0) {
+    // two register sets: the activations of stage s+2 are requested at the top of stage s and written to LDS at the
+    // end of stage s+1 (one stage of cover is not enough for an HBM miss at 2 waves per SIMD)
+    float bst[2][NIT][8];
+    auto load_b = [&](int c0, auto set_tag) {
+        constexpr int Q = decltype(set_tag)::value;
 #pragma unroll
         for (int r = 0; r < NIT; ++r) {
             const int c = c0 + 8 * (g0 + r * (NT / BN));
 #pragma unroll
             for (int m = 0; m < 8; ++m)
-                bst[r][m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                bst[Q][r][m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                     rsrc_b, c + m < d.C ? boff : OOB, (c0 + 8 * r * (NT / BN) + m) * chw4, 0));
-            if constexpr (TF) {
-                const int vo = c < d.C ? c * 4 : OOB;   // C % 16 == 0: an octet is inside or outside as a whole
-                tsc[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, vo, 0, 0);
-                tsc[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, vo, 16, 0);
-                tsh[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, vo, 0, 0);
-                tsh[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, vo, 16, 0);
-            }
         }
     };
-    auto store_b = [&](u32x4* dst) {
+    // a staging thread's k-octet is the same for its whole wavefront (BN >= 64): the fused transform's constants are
+    // scalar loads
+    const int g0u = __builtin_amdgcn_readfirstlane(g0);
+    auto store_b = [&](int c0, u32x4* dst, auto set_tag) {
+        constexpr int Q = decltype(set_tag)::value;
 #pragma unroll
         for (int r = 0; r < NIT; ++r) {
             u32x4 hi, mid, lo;
@@ -265,9 +262,11 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(PwDesc d, OutDesc 
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int m = 2 * q + u;
-                    float t = bst[r][m];
+                    float t = bst[Q][r][m];
                     if constexpr (TF) {
-                        t = fmaf(t, __uint_as_float(tsc[r][m >> 2][m & 3]), __uint_as_float(tsh[r][m >> 2][m & 3]));
+                        const int c = c0 + 8 * (g0u + r * (NT / BN)) + m;
+                        const int cc = c < d.C ? c : 0;
+                        t = fmaf(t, d.scale[cc], d.shift[cc]);
                         t = d.relu ? fmaxf(t, 0.f) : t;
                         t = bok ? t : 0.f;
                     }
@@ -284,22 +283,16 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(PwDesc d, OutDesc 
         }
     };
 
-    // ---- weights: fp32 rows straight from global memory, split in registers
+    // ---- weights: pre-split planes ws[chunk][plane][row][16 bf16]; lane (row, h) takes 16 bytes per plane
     const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(d.w, d.nw);
     const int row = i0 + wm * 32 + l31;
-    const int aoff = row < d.M ? (row * d.C + lh * 8) * 4 : OOB;
-    auto load_a = [&](u32x4 (&raw)[2], int c) {
-        const int vo = c < d.C ? aoff : OOB;
-        raw[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, c * 4, 0);
-        raw[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo + 16, c * 4, 0);
-    };
-    auto split_a = [&](u32x4 (&dst)[3], const u32x4 (&raw)[2]) {
+    const int aoff = row < d.M ? row * 32 + lh * 16 : OOB;
+    const int aplane = d.M * 32;                       // bytes per (chunk, plane) slab
+    const int nchunk = (d.C + 15) / 16;
+    auto load_a = [&](u32x4 (&dst)[3], int ch) {      // ch >= nchunk: zeros
+        const int vo = ch < nchunk ? aoff : OOB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t h, mm, l;
-            split3(__uint_as_float(raw[q >> 1][(2 * q) & 3]), __uint_as_float(raw[q >> 1][(2 * q + 1) & 3]), h, mm, l);
-            dst[0][q] = h; dst[1][q] = mm; dst[2][q] = l;
-        }
+        for (int p = 0; p < 3; ++p) dst[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, (ch * 3 + p) * aplane, 0);
     };
 
     f32x16 acc[1][NI];
@@ -315,58 +308,74 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(PwDesc d, OutDesc 
         for (int q = 0; q < 3; ++q) dst[q] = p[q * 4 * BN];
     };
 
-    u32x4 araw[2];
     u32x4 areg[2][3];
     u32x4 bfr[2][3];
 
-    load_b(0);
-    load_a(araw, 0);
-    store_b(Bs(0));
-    split_a(areg[0], araw);
-    load_a(araw, 16);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    load_b(0, S0{});
+    load_b(PW_KS, S1{});
+    load_a(areg[0], 0);
+    store_b(0, Bs(0), S0{});
     __syncthreads();
     read_b(bfr[0], Bs(0), 0, 0);
 
-    for (int s = 0; s < nstage; ++s) {
-        const int c0 = s * PW_KS;
-        const u32x4* bcur = Bs(s & 1);
-        u32x4* bnext = Bs((s + 1) & 1);
-        load_b(c0 + PW_KS);
+    // stage s: LDS buffer s & 1, register set s & 1 is free again (its data went to LDS one stage ago)
+    auto stage = [&](int s, auto cur_tag) {
+        constexpr int CUR = decltype(cur_tag)::value;
+        const u32x4* bcur = Bs(CUR);
+        u32x4* bnext = Bs(CUR ^ 1);
+        load_b((s + 2) * PW_KS, std::integral_constant<int, CUR>{});
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            // araw holds the fp32 weights of the NEXT sub-chunk (loaded one sub-chunk ago)
+            load_a(areg[t ^ 1], 2 * s + t + 1);        // next sub-chunk's weights, one sub-chunk ahead
 #pragma unroll
             for (int b = 0; b < NI; ++b) {
                 const int fcur = (t * NI + b) & 1, fnxt = fcur ^ 1;
                 if (b + 1 < NI) read_b(bfr[fnxt], bcur, t, b + 1);
                 else if (t == 0) read_b(bfr[fnxt], bcur, 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (b == 0) {                           // next sub-chunk's operands: split now, refill the raw buffer
-                    split_a(areg[t ^ 1], araw);
-                    load_a(araw, c0 + 16 * t + 32);
-                }
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[fcur][0]);
-                const bf16x8 bm_ = __builtin_bit_cast(bf16x8, bfr[fcur][1]);
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, bfr[fcur][2]);
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, areg[t][0]);
-                const bf16x8 am = __builtin_bit_cast(bf16x8, areg[t][1]);
-                const bf16x8 al = __builtin_bit_cast(bf16x8, areg[t][2]);
-                f32x16 c = acc[0][b];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);   // small terms first
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm_, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm_, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-                acc[0][b] = c;
+                acc[0][b] = mfma_split(areg[t], bfr[fcur], acc[0][b]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        store_b(bnext);
+        store_b((s + 1) * PW_KS, bnext, std::integral_constant<int, CUR ^ 1>{});
         __syncthreads();
         read_b(bfr[0], bnext, 0, 0);
+    };
+    for (int s = 0; s < nstage; s += 2) {
+        stage(s, S0{});
+        if (s + 1 < nstage) stage(s + 1, S1{});
     }
     store_tile<1, NI, BM, BN, WM, WN>(acc, dc, d.M, d.npix, i0, j0, 0);
+}
+
+// ws[ch][plane][i][16 bf16]: the three bf16 terms of element (i, c) = transposed ? w[c][i] : w[i][c]; w is the
+// forward weight [Cout][Cin] (M = Cout, C = Cin forward; M = Cin, C = Cout for the data gradient)
+__global__ void w1x1_split_kernel(const float* __restrict__ w, uint16_t* __restrict__ ws, int M, int C, int transposed) {
+    const int nchunk = (C + 15) / 16;
+    const int64_t n = (int64_t)nchunk * M * 16;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int k16 = e & 15;
+        const int64_t r = e >> 4;
+        const int i = r % M, ch = r / M;
+        const int c = ch * 16 + k16;
+        const float v = c < C ? (transposed ? w[(int64_t)c * M + i] : w[(int64_t)i * C + c]) : 0.f;
+        uint32_t hi, mid, lo;
+        split3(v, 0.f, hi, mid, lo);
+        const int64_t base = ((int64_t)ch * 3 * M + i) * 16 + k16;
+        ws[base] = (uint16_t)hi;
+        ws[base + (int64_t)M * 16] = (uint16_t)mid;
+        ws[base + (int64_t)2 * M * 16] = (uint16_t)lo;
+    }
+}
+// fp32 transpose for the fp32-MFMA twin: ws[i][c] = w[c][i]
+__global__ void w1x1_t_kernel(const float* __restrict__ w, float* __restrict__ ws, int M, int C) {
+    const int64_t n = (int64_t)M * C;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = e % C, i = e / C;
+        ws[e] = w[(int64_t)c * M + i];
+    }
 }
 
 template <int WM, int BN, bool TF>
@@ -395,18 +404,24 @@ static void launch_pw_cfg(int cfg, const PwDesc& d, const OutDesc& dc, hipStream
 
 using namespace scat;
 
+extern "C" int64_t scat_conv1x1_s1_ws(int M, int C) { return (int64_t)M * ((C + 15) / 16 * 16) * 6; }
+
 // dst[B,M,HW] (+)= A[M,C] . f(src[B,C,HW]),  f = relu(x*scale+shift) when scale is given.
-//   forward:        A = w[Cout][Cin]            (C = Cin,  M = Cout)
-//   data gradient:  A = scat_conv2d_wt(w) = [Cin][Cout], src = dy   (C = Cout, M = Cin)
-// Needs C % 16 == 0 and 16-B aligned A; callers fall back to scat_conv2d_fwd / scat_conv2d_dgrad otherwise.
-extern "C" int scat_conv1x1_s1(const float* src, const float* a, float* dst, int B, int C, int HW, int M,
-                               const float* bias, const float* in_scale, const float* in_shift, int in_relu,
-                               int accumulate, void* stream) {
-    SCAT_REQUIRE(src && a && dst, SCAT_E_ARG, "scat_conv1x1_s1: null pointer");
+//   transposed = 0, forward:        w = [M][C]  (M = Cout, C = Cin)
+//   transposed = 1, data gradient:  w = [C][M]  (the forward weight; M = Cin, C = Cout), src = dy
+// ws: scat_conv1x1_s1_ws(M, C) bytes (the weights' bf16 terms, or their fp32 transpose).
+// Needs C % 16 == 0 and 16-B aligned w/src; callers fall back to scat_conv2d_fwd / scat_conv2d_dgrad otherwise.
+extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int B, int C, int HW, int M,
+                               int transposed, const float* bias, const float* in_scale, const float* in_shift,
+                               int in_relu, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+    SCAT_REQUIRE(src && w && dst, SCAT_E_ARG, "scat_conv1x1_s1: null pointer");
+    SCAT_REQUIRE(ws && ws_bytes >= scat_conv1x1_s1_ws(M, C), SCAT_E_WORKSPACE, "scat_conv1x1_s1: workspace too small");
+    const float* a = w;
     SCAT_REQUIRE(B > 0 && C > 0 && HW > 0 && M > 0, SCAT_E_SHAPE, "scat_conv1x1_s1: non-positive dimension");
     SCAT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), SCAT_E_ARG, "scat_conv1x1_s1: scale/shift pair");
     SCAT_REQUIRE(C % 16 == 0, SCAT_E_SHAPE, "scat_conv1x1_s1: channels must be a multiple of 16");
-    SCAT_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)src & 15) == 0, SCAT_E_ARG, "scat_conv1x1_s1: 16-B alignment");
+    SCAT_REQUIRE(((uintptr_t)w & 15) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)ws & 15) == 0, SCAT_E_ARG,
+                 "scat_conv1x1_s1: 16-B alignment");
     SCAT_REQUIRE(!in_scale || (((uintptr_t)in_scale & 15) == 0 && ((uintptr_t)in_shift & 15) == 0), SCAT_E_ARG,
                  "scat_conv1x1_s1: scale/shift must be 16-B aligned");
     SCAT_REQUIRE(fits_i32((int64_t)B * C * HW * 4) && fits_i32((int64_t)B * M * HW * 4) && fits_i32((int64_t)M * C * 4),
@@ -423,7 +438,12 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* a, float* dst, int
     int cfg = (M > 64 && tiles(128, 128) >= 1024) ? 0 : 2;   // measured: 64x128 never wins at batch 96
     if (tuning() >= 1 && tuning() <= 3) cfg = tuning() - 1;
     static const char* const names[] = {"128x128", "64x128", "64x64"};
+    const int64_t nel = (int64_t)M * ((C + 15) / 16 * 16);
+    const int rblocks = (int)((nel + 255) / 256 < 2048 ? (nel + 255) / 256 : 2048);
     if (math_mode() == 1) {
+        hipLaunchKernelGGL(w1x1_split_kernel, dim3(rblocks), dim3(256), 0, st, w, (uint16_t*)ws, M, C, transposed);
+        d.w = (const float*)ws;
+        d.nw = (nel * 6 + 3) / 4;
         if (!(tuning() >= 1 && tuning() <= 3)) cfg = M > 64 ? 0 : 1;   // measured at batch 96: 64x64 never wins
         set_kernel_label("conv1x1_split_%sx32%s", names[cfg], in_scale ? "_tf" : "");
         if (in_scale) {
@@ -437,6 +457,10 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* a, float* dst, int
         }
         SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
         return SCAT_OK;
+    }
+    if (transposed) {
+        hipLaunchKernelGGL(w1x1_t_kernel, dim3(rblocks), dim3(256), 0, st, w, (float*)ws, M, C);
+        d.w = (const float*)ws;
     }
     const bool v4 = HW % 4 == 0;
     set_kernel_label("conv1x1_pw_%sx32%s%s", names[cfg], v4 ? "_b4" : "", in_scale ? "_tf" : "");

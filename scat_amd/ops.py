@@ -103,8 +103,9 @@ def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, b
     OH, OW = conv_out_hw(H, W, KH, stride, pad)
     y = out if out is not None else torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
     if _pw_ok(KH, KW, stride, pad, Cin, x, w, in_scale, in_shift):
-        _prof(2.0 * B * OH * OW * Cout * Cin, lib().scat_conv1x1_s1, _p(x), _p(w), _p(y), B, Cin, H * W, Cout, _p(bias),
-              _p(in_scale), _p(in_shift), int(in_relu), 0, _stream())
+        ws = workspace(lib().scat_conv1x1_s1_ws(Cout, Cin), x.device, "wt")
+        _prof(2.0 * B * OH * OW * Cout * Cin, lib().scat_conv1x1_s1, _p(x), _p(w), _p(y), B, Cin, H * W, Cout, 0,
+              _p(bias), _p(in_scale), _p(in_shift), int(in_relu), 0, _p(ws), ws.numel(), _stream())
         return y
     if _halo_ok(KH, KW, stride, pad, Cin, W) and bias is None:
         ws = workspace(lib().scat_conv3x3_s1_ws(Cout, Cin), x.device, "wt")
@@ -154,13 +155,14 @@ def conv2d_dgrad_w(dy, w, x_shape, stride, pad, out=None, accumulate=False):
         _prof(2.0 * B * H * W * Cout * Cin * 9, lib().scat_conv3x3_s1, _p(dy), _p(w), _p(dx), B, Cin, H, W, Cout, 1,
               0, 0, 0, int(accumulate), _p(ws), ws.numel(), _stream())
         return dx
+    if _pw_ok(KH, KW, stride, pad, Cout, dy, w, out):
+        dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+        ws = workspace(lib().scat_conv1x1_s1_ws(Cin, Cout), dy.device, "wt")
+        _prof(2.0 * B * H * W * Cout * Cin, lib().scat_conv1x1_s1, _p(dy), _p(w), _p(dx), B, Cout, H * W, Cin, 1, 0, 0,
+              0, 0, int(accumulate), _p(ws), ws.numel(), _stream())
+        return dx
     wt = conv2d_wt(w, out=workspace(4 * w.numel(), dy.device, "wt")[: 4 * w.numel()].view(torch.float32)
                    .view(Cin, Cout * KH * KW))
-    if _pw_ok(KH, KW, stride, pad, Cout, dy, wt, out):
-        dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
-        _prof(2.0 * B * H * W * Cout * Cin, lib().scat_conv1x1_s1, _p(dy), _p(wt), _p(dx), B, Cout, H * W, Cin, 0, 0, 0,
-              0, int(accumulate), _stream())
-        return dx
     return conv2d_dgrad(dy, wt, x_shape, tuple(w.shape), stride, pad, out=out, accumulate=accumulate)
 
 

@@ -15,7 +15,7 @@ for d in sys.argv[1:]:
     seen = collections.Counter()
     print("==", d)
     for (did, name), c in disp.items():
-        if "gemm_kernel" not in name and "halo" not in name:
+        if not any(k in name for k in ("gemm_kernel", "halo", "split_kernel", "conv1x1_kernel")) or "wt3x3" in name:
             continue
         short = re.sub(r"scat::|Loader|void ", "", name)[:70]
         seen[short] += 1
