@@ -64,6 +64,13 @@ int64_t scat_conv3x3_s1_ws(int Cout, int Cin);
 int scat_conv3x3_s1(const float* src, const float* w, float* dst, int B, int Cin, int H, int W, int Cout,
                     int transposed, const float* in_scale, const float* in_shift, int in_relu, int accumulate,
                     void* ws, int64_t ws_bytes, void* stream);
+/* Forward conv (1x1 / 3x3, stride 1 or 2) on the split-operand taps kernel: contraction ordered (tap, channel),
+ * weights re-laid and split per call into ws (scat_conv2d_fwd_split_ws bytes).  Needs scat_get_math_mode() == 1 and
+ * Cin % 16 == 0.  The library's path for the stride-2 convolutions (models/resnet.py:68,131-135). */
+int64_t scat_conv2d_fwd_split_ws(int Cout, int Cin, int KH, int KW);
+int scat_conv2d_fwd_split(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
+                          int Cout, int KH, int KW, int stride, int pad, const float* in_scale, const float* in_shift,
+                          int in_relu, void* ws, int64_t ws_bytes, void* stream);
 /* Pointwise (1x1, stride 1, pad 0) conv: dst[B,M,HW] (+)= A[M,C] . relu(src[B,C,HW]*scale+shift) (+ bias[M]).
  * Weights go straight from L2 to the MFMA operand registers, activations through LDS 32 channels per barrier.
  * transposed = 0 (forward): w = [M,C] = the conv weight [Cout,Cin];  transposed = 1 (data gradient): w = [C,M] is

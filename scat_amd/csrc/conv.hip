@@ -182,7 +182,9 @@ extern "C" int scat_conv2d_dgrad(const float* dy, const float* wt, float* dx, in
 }
 
 extern "C" int64_t scat_conv2d_dgrad_s2_ws(int Cin, int Cout, int KH, int KW) {
-    return (int64_t)Cin * Cout * KH * KW * sizeof(float);
+    const int64_t f32 = (int64_t)Cin * Cout * KH * KW * sizeof(float);
+    const int64_t split = taps_split_ws(Cin, Cout, KH == 1 ? 1 : 4);   // largest parity class: 2x2 taps
+    return f32 > split ? f32 : split;
 }
 
 extern "C" int scat_conv2d_dgrad_s2(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W,
@@ -211,6 +213,21 @@ extern "C" int scat_conv2d_dgrad_s2(const float* dy, const float* w, float* dx, 
             const int QH = (H - py + 1) / 2, QW = (W - px + 1) / 2;         // input pixels in this class
             if (KHc <= 0 || KWc <= 0 || QH <= 0 || QW <= 0) continue;       // 1x1: only class (0,0) has a tap
             const int KKc = KHc * KWc, K = Cout * KKc, N = B * QH * QW;
+            if (math_mode() == 1 && Cout % 16 == 0 && ((uintptr_t)ws & 15) == 0) {
+                // split-operand taps kernel: class pixel (qy, qx), tap (kky, kkx) reads dy(qy + (py+pad)/2 - kky, ...)
+                TapsGeom g{};
+                g.H = OH; g.W = OW; g.OH = QH; g.OW = QW; g.a = 1; g.tb = -1;
+                g.c0y = (py + pad) >> 1; g.c0x = (px + pad) >> 1;
+                g.KHt = KHc; g.KWt = KWc; g.KH = KH; g.KW = KW; g.kh0 = kh0; g.kw0 = kw0; g.ts = 2; g.transposed = 1;
+                OutDesc dc{};
+                dc.p = dx; dc.mode = 2; dc.I = Cin; dc.J = N; dc.C = Cin; dc.HW = H * W; dc.W = W; dc.QW = QW;
+                dc.sub_s = 2; dc.sub_y = py; dc.sub_x = px; dc.dQHW = FastDiv::make(QH * QW);
+                dc.dQW = FastDiv::make(QW); dc.accumulate = accumulate; dc.n = (int64_t)B * Cin * H * W;
+                char label[40];
+                snprintf(label, sizeof label, "dgrad_s2_class%dx%d", KHc, KWc);
+                taps_split_launch(g, dy, w, dc, B, Cout, Cin, nullptr, nullptr, 0, ws, label, st);
+                continue;
+            }
             int64_t nw = (int64_t)Cin * K;
             int blocks = (int)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048);
             hipLaunchKernelGGL(wt_class_kernel, dim3(blocks), dim3(256), 0, st, w, wtc, Cout, Cin, KH, KW, kh0, kw0,

@@ -24,9 +24,13 @@ struct PwDesc {
     const float* scale;   // optional fused input transform, per source channel
     const float* shift;
     int relu;
-    int C, M, HW, npix;
+    int C, M, HW, npix;   // HW: source plane; npix: columns of the contraction = B * OHW
     FastDiv dHW;
     int64_t nsrc, nw;
+    // split kernel only — taps: source (y, x) of column pixel (oy, ox) and tap (th, tw) is
+    // (oy*a + th*tb + c0y, ox*a + tw*tb + c0x); a 1x1/stride-1 conv has ntap = 1, a = 1, OHW = HW
+    int ntap, KWt, a, tb, c0y, c0x, H, W, OW, OHW;
+    FastDiv dOHW, dOW;
 };
 
 constexpr int PW_KS = 32;     // channels per LDS stage (two 16-channel sub-chunks)
@@ -219,40 +223,57 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int nstage = (d.C + PW_KS - 1) / PW_KS;
+    const int nsc = (d.C + PW_KS - 1) / PW_KS;       // 32-channel stages per tap
+    const int nstage = d.ntap * nsc;                   // contraction order: (tap, channel)
 
     // ---- activation staging: this thread's pixel, k-octets g0 + r*(NT/BN)
     const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(d.src, d.nsrc);
     const int pcol = tid % BN, g0 = tid / BN;
     const int chw4 = d.HW * 4;
-    int boff;
+    int boff;                                          // byte offset of (n, channel 8*g0, tap (0,0)); only used under pmask
+    uint32_t pmask = 0;                                // taps that fall inside the source plane for this pixel
     bool bok;
     {
         const int j = j0 + pcol;
         bok = j < d.npix;
         const uint32_t jj = bok ? (uint32_t)j : 0u;
-        const uint32_t n = d.dHW.div(jj);
-        boff = bok ? (int)((n * (uint32_t)d.C * (uint32_t)d.HW + (jj - n * (uint32_t)d.HW)) * 4u) + 8 * g0 * chw4 : OOB;
+        const uint32_t n = d.dOHW.div(jj);
+        const uint32_t r = jj - n * (uint32_t)d.OHW;
+        const int oy = (int)d.dOW.div(r), ox = (int)r - oy * d.OW;
+        const int sy0 = oy * d.a + d.c0y, sx0 = ox * d.a + d.c0x;
+        boff = ((int)n * d.C * d.HW + sy0 * d.W + sx0) * 4 + 8 * g0 * chw4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int th = t / d.KWt, tw = t - th * d.KWt;
+            const bool ok = bok && t < d.ntap && (unsigned)(sy0 + th * d.tb) < (unsigned)d.H &&
+                            (unsigned)(sx0 + tw * d.tb) < (unsigned)d.W;
+            pmask |= (ok ? 1u : 0u) << t;
+        }
     }
     // two register sets: the activations of stage s+2 are requested at the top of stage s and written to LDS at the
     // end of stage s+1 (one stage of cover is not enough for an HBM miss at 2 waves per SIMD)
     float bst[2][NIT][8];
-    auto load_b = [&](int c0, auto set_tag) {
+    auto load_b = [&](int st, auto set_tag) {         // st >= nstage: every lane reads 0
         constexpr int Q = decltype(set_tag)::value;
+        const int tap = st / nsc, c0 = (st - tap * nsc) * PW_KS;
+        const int th = tap / d.KWt, tw = tap - th * d.KWt;
+        const int vbase = ((pmask >> (tap < 9 ? tap : 9)) & 1u) && st < nstage ? boff + (th * d.W + tw) * d.tb * 4 : OOB;
 #pragma unroll
         for (int r = 0; r < NIT; ++r) {
             const int c = c0 + 8 * (g0 + r * (NT / BN));
 #pragma unroll
             for (int m = 0; m < 8; ++m)
                 bst[Q][r][m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                    rsrc_b, c + m < d.C ? boff : OOB, (c0 + 8 * r * (NT / BN) + m) * chw4, 0));
+                    rsrc_b, c + m < d.C ? vbase : OOB, (c0 + 8 * r * (NT / BN) + m) * chw4, 0));
         }
     };
     // a staging thread's k-octet is the same for its whole wavefront (BN >= 64): the fused transform's constants are
     // scalar loads
     const int g0u = __builtin_amdgcn_readfirstlane(g0);
-    auto store_b = [&](int c0, u32x4* dst, auto set_tag) {
+    auto store_b = [&](int st, u32x4* dst, auto set_tag) {
         constexpr int Q = decltype(set_tag)::value;
+        const int tap = st / nsc, c0 = (st - tap * nsc) * PW_KS;
+        const bool live = (pmask >> (tap < 9 ? tap : 9)) & 1u;   // padding must stay zero AFTER the transform
 #pragma unroll
         for (int r = 0; r < NIT; ++r) {
             u32x4 hi, mid, lo;
@@ -268,7 +289,7 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
                         const int cc = c < d.C ? c : 0;
                         t = fmaf(t, d.scale[cc], d.shift[cc]);
                         t = d.relu ? fmaxf(t, 0.f) : t;
-                        t = bok ? t : 0.f;
+                        t = live ? t : 0.f;
                     }
                     x[u] = t;
                 }
@@ -289,10 +310,14 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
     const int aoff = row < d.M ? row * 32 + lh * 16 : OOB;
     const int aplane = d.M * 32;                       // bytes per (chunk, plane) slab
     const int nchunk = (d.C + 15) / 16;
-    auto load_a = [&](u32x4 (&dst)[3], int ch) {      // ch >= nchunk: zeros
-        const int vo = ch < nchunk ? aoff : OOB;
+    // sub-chunk q = 2*stage + t of the (tap, channel) order -> slab (tap*nchunk + chunk); a stage's second sub-chunk
+    // may lie past the channels (C % 32 == 16), the sub-chunk after the last stage always does: zeros
+    auto load_a = [&](u32x4 (&dst)[3], int q) {
+        const int st = q >> 1, tap = st / nsc, ch = (st - tap * nsc) * 2 + (q & 1);
+        const int vo = (ch < nchunk && st < nstage) ? aoff : OOB;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) dst[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, (ch * 3 + p) * aplane, 0);
+        for (int p = 0; p < 3; ++p)
+            dst[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, ((tap * nchunk + ch) * 3 + p) * aplane, 0);
     };
 
     f32x16 acc[1][NI];
@@ -314,7 +339,7 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     load_b(0, S0{});
-    load_b(PW_KS, S1{});
+    load_b(1, S1{});
     load_a(areg[0], 0);
     store_b(0, Bs(0), S0{});
     __syncthreads();
@@ -325,7 +350,7 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
         constexpr int CUR = decltype(cur_tag)::value;
         const u32x4* bcur = Bs(CUR);
         u32x4* bnext = Bs(CUR ^ 1);
-        load_b((s + 2) * PW_KS, std::integral_constant<int, CUR>{});
+        load_b(s + 2, std::integral_constant<int, CUR>{});
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             load_a(areg[t ^ 1], 2 * s + t + 1);        // next sub-chunk's weights, one sub-chunk ahead
@@ -339,7 +364,7 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        store_b((s + 1) * PW_KS, bnext, std::integral_constant<int, CUR ^ 1>{});
+        store_b(s + 1, bnext, std::integral_constant<int, CUR ^ 1>{});
         __syncthreads();
         read_b(bfr[0], bnext, 0, 0);
     };
@@ -350,20 +375,26 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
     store_tile<1, NI, BM, BN, WM, WN>(acc, dc, d.M, d.npix, i0, j0, 0);
 }
 
-// ws[ch][plane][i][16 bf16]: the three bf16 terms of element (i, c) = transposed ? w[c][i] : w[i][c]; w is the
-// forward weight [Cout][Cin] (M = Cout, C = Cin forward; M = Cin, C = Cout for the data gradient)
-__global__ void w1x1_split_kernel(const float* __restrict__ w, uint16_t* __restrict__ ws, int M, int C, int transposed) {
+// ws[tap][ch][plane][i][16 bf16]: the three bf16 terms of element (i, c, tap).  w is the conv weight
+// [Cout][Cin][KH][KW]; forward: (i, c) = (co, ci); transposed (data gradient): (i, c) = (ci, co).  Tap t of the ntap
+// listed ones is (kh0 + ts*(t / KWt), kw0 + ts*(t % KWt)).
+__global__ void w_taps_split_kernel(const float* __restrict__ w, uint16_t* __restrict__ ws, int M, int C, int transposed,
+                                    int KH, int KW, int ntap, int KWt, int kh0, int kw0, int ts) {
     const int nchunk = (C + 15) / 16;
-    const int64_t n = (int64_t)nchunk * M * 16;
+    const int64_t n = (int64_t)ntap * nchunk * M * 16;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const int k16 = e & 15;
-        const int64_t r = e >> 4;
-        const int i = r % M, ch = r / M;
+        int64_t r = e >> 4;
+        const int i = r % M;
+        r /= M;                                          // r = tap * nchunk + ch
+        const int ch = r % nchunk, t = r / nchunk;
         const int c = ch * 16 + k16;
-        const float v = c < C ? (transposed ? w[(int64_t)c * M + i] : w[(int64_t)i * C + c]) : 0.f;
+        const int kh = kh0 + ts * (t / KWt), kw = kw0 + ts * (t % KWt);
+        const int64_t pair = transposed ? (int64_t)c * M + i : (int64_t)i * C + c;
+        const float v = c < C ? w[(pair * KH + kh) * KW + kw] : 0.f;
         uint32_t hi, mid, lo;
         split3(v, 0.f, hi, mid, lo);
-        const int64_t base = ((int64_t)ch * 3 * M + i) * 16 + k16;
+        const int64_t base = (r * 3 * M + i) * 16 + k16;
         ws[base] = (uint16_t)hi;
         ws[base + (int64_t)M * 16] = (uint16_t)mid;
         ws[base + (int64_t)2 * M * 16] = (uint16_t)lo;
@@ -400,9 +431,77 @@ static void launch_pw_cfg(int cfg, const PwDesc& d, const OutDesc& dc, hipStream
     else launch_pw<64, 64, V4, TF>(d, dc, st);
 }
 
+// General entry of the split kernel: dst (+)= sum over the listed taps and C source channels.
+//   source pixel of column (oy, ox), tap (th, tw): (oy*a + th*tb + c0y, ox*a + tw*tb + c0x) of src[B][C][H][W]
+//   weights: taps (kh0 + ts*th, kw0 + ts*tw) of the conv weight w[Cout][Cin][KH][KW], (row, channel) = (co, ci) or,
+//   transposed, (ci, co).  ws >= taps_split_ws(M, C, KHt*KWt) bytes.
+int64_t taps_split_ws(int M, int C, int ntap) { return (int64_t)ntap * M * ((C + 15) / 16 * 16) * 6; }
+
+void taps_split_launch(const TapsGeom& g, const float* src, const float* w, const OutDesc& dc, int B, int C, int M,
+                       const float* in_scale, const float* in_shift, int in_relu, void* ws, const char* label,
+                       hipStream_t st) {
+    PwDesc d{};
+    d.src = src; d.scale = in_scale; d.shift = in_shift; d.relu = in_scale ? in_relu : 0;
+    d.C = C; d.M = M; d.HW = g.H * g.W; d.npix = B * g.OH * g.OW; d.dHW = FastDiv::make(d.HW);
+    d.ntap = g.KHt * g.KWt; d.KWt = g.KWt; d.a = g.a; d.tb = g.tb; d.c0y = g.c0y; d.c0x = g.c0x; d.H = g.H; d.W = g.W;
+    d.OW = g.OW; d.OHW = g.OH * g.OW; d.dOHW = FastDiv::make(d.OHW); d.dOW = FastDiv::make(g.OW);
+    d.nsrc = (int64_t)B * C * d.HW;
+    const int64_t nel = (int64_t)d.ntap * M * ((C + 15) / 16 * 16);
+    const int rblocks = (int)((nel + 255) / 256 < 2048 ? (nel + 255) / 256 : 2048);
+    hipLaunchKernelGGL(w_taps_split_kernel, dim3(rblocks), dim3(256), 0, st, w, (uint16_t*)ws, M, C, g.transposed, g.KH,
+                       g.KW, d.ntap, g.KWt, g.kh0, g.kw0, g.ts);
+    d.w = (const float*)ws;
+    d.nw = (nel * 6 + 3) / 4;
+    int cfg = M > 64 ? 0 : 1;
+    if ((int64_t)cdiv(M, 128) * cdiv(d.npix, 128) < 256 && (int64_t)cdiv(M, 64) * cdiv(d.npix, 64) >= 256) cfg = 2;
+    if (tuning() >= 1 && tuning() <= 3) cfg = tuning() - 1;
+    static const char* const names[] = {"128x128", "64x128", "64x64"};
+    set_kernel_label("%s_split_%sx32%s", label, names[cfg], in_scale ? "_tf" : "");
+    if (in_scale) {
+        if (cfg == 0) launch_pw_split<4, 128, true>(d, dc, st);
+        else if (cfg == 1) launch_pw_split<2, 128, true>(d, dc, st);
+        else launch_pw_split<2, 64, true>(d, dc, st);
+    } else {
+        if (cfg == 0) launch_pw_split<4, 128, false>(d, dc, st);
+        else if (cfg == 1) launch_pw_split<2, 128, false>(d, dc, st);
+        else launch_pw_split<2, 64, false>(d, dc, st);
+    }
+}
+
 }  // namespace scat
 
 using namespace scat;
+
+extern "C" int64_t scat_conv2d_fwd_split_ws(int Cout, int Cin, int KH, int KW) {
+    return taps_split_ws(Cout, Cin, KH * KW);
+}
+
+// Forward convolution (1x1 or 3x3, stride 1 or 2) on the taps kernel: contraction ordered (tap, channel), one
+// 32-channel activation stage of one tap per barrier.  Split-operand products only (scat_get_math_mode() == 1);
+// Cin % 16 == 0.  Used for the stride-2 convolutions (3x3/s1 has the halo kernel, 1x1/s1 scat_conv1x1_s1).
+extern "C" int scat_conv2d_fwd_split(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H,
+                                     int W, int Cout, int KH, int KW, int stride, int pad, const float* in_scale,
+                                     const float* in_shift, int in_relu, void* ws, int64_t ws_bytes, void* stream) {
+    int OH, OW;
+    if (int e = check_geom("scat_conv2d_fwd_split", B, Cin, H, W, Cout, KH, KW, stride, pad, &OH, &OW)) return e;
+    SCAT_REQUIRE(x && w && y, SCAT_E_ARG, "scat_conv2d_fwd_split: null pointer");
+    SCAT_REQUIRE(math_mode() == 1, SCAT_E_ARG, "scat_conv2d_fwd_split: needs the split-operand product mode");
+    SCAT_REQUIRE(KH <= 3 && Cin % 16 == 0, SCAT_E_SHAPE, "scat_conv2d_fwd_split: 1x1/3x3 and Cin % 16 == 0 only");
+    SCAT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), SCAT_E_ARG, "scat_conv2d_fwd_split: scale/shift pair");
+    SCAT_REQUIRE(ws && ws_bytes >= scat_conv2d_fwd_split_ws(Cout, Cin, KH, KW) && ((uintptr_t)ws & 15) == 0,
+                 SCAT_E_WORKSPACE, "scat_conv2d_fwd_split: workspace too small / unaligned");
+    TapsGeom g{};
+    g.H = H; g.W = W; g.OH = OH; g.OW = OW; g.a = stride; g.tb = 1; g.c0y = -pad; g.c0x = -pad;
+    g.KHt = KH; g.KWt = KW; g.KH = KH; g.KW = KW; g.kh0 = 0; g.kw0 = 0; g.ts = 1; g.transposed = 0;
+    OutDesc dc{};
+    dc.p = y; dc.mode = 1; dc.I = Cout; dc.J = B * OH * OW; dc.C = Cout; dc.HW = OH * OW;
+    dc.dHW = FastDiv::make(OH * OW); dc.bias = bias; dc.bias_mode = bias ? 1 : 0; dc.n = (int64_t)B * Cout * OH * OW;
+    char label[32];
+    snprintf(label, sizeof label, "conv%dx%d_s%d", KH, KW, stride);
+    taps_split_launch(g, x, w, dc, B, Cin, Cout, in_scale, in_shift, in_relu, ws, label, (hipStream_t)stream);
+    SCAT_LAUNCH_CHECK("scat_conv2d_fwd_split");
+    return SCAT_OK;
+}
 
 extern "C" int64_t scat_conv1x1_s1_ws(int M, int C) { return (int64_t)M * ((C + 15) / 16 * 16) * 6; }
 
@@ -430,6 +529,8 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
     PwDesc d{};
     d.src = src; d.w = a; d.scale = in_scale; d.shift = in_shift; d.relu = in_scale ? in_relu : 0;
     d.C = C; d.M = M; d.HW = HW; d.npix = B * HW; d.dHW = FastDiv::make(HW);
+    d.ntap = 1; d.KWt = 1; d.a = 1; d.tb = 1; d.c0y = 0; d.c0x = 0; d.H = 1; d.W = HW; d.OW = HW; d.OHW = HW;
+    d.dOHW = FastDiv::make(HW); d.dOW = FastDiv::make(HW);
     d.nsrc = (int64_t)B * C * HW; d.nw = (int64_t)M * C;
     OutDesc dc{};
     dc.p = dst; dc.mode = 1; dc.I = M; dc.J = d.npix; dc.C = M; dc.HW = HW; dc.dHW = FastDiv::make(HW);
@@ -441,7 +542,8 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
     const int64_t nel = (int64_t)M * ((C + 15) / 16 * 16);
     const int rblocks = (int)((nel + 255) / 256 < 2048 ? (nel + 255) / 256 : 2048);
     if (math_mode() == 1) {
-        hipLaunchKernelGGL(w1x1_split_kernel, dim3(rblocks), dim3(256), 0, st, w, (uint16_t*)ws, M, C, transposed);
+        hipLaunchKernelGGL(w_taps_split_kernel, dim3(rblocks), dim3(256), 0, st, w, (uint16_t*)ws, M, C, transposed, 1, 1,
+                           1, 1, 0, 0, 1);
         d.w = (const float*)ws;
         d.nw = (nel * 6 + 3) / 4;
         if (!(tuning() >= 1 && tuning() <= 3)) cfg = M > 64 ? 0 : 1;   // measured at batch 96: 64x64 never wins

@@ -20,13 +20,27 @@ static inline int check_geom(const char* who, int B, int Cin, int H, int W, int 
     return SCAT_OK;
 }
 
+// split-operand taps kernel (conv1x1.hip): see taps_split_launch
+struct TapsGeom {
+    int H, W;             // source plane
+    int OH, OW;           // pixel grid of the contraction's columns
+    int a, tb, c0y, c0x;  // source (y, x) = (oy*a + th*tb + c0y, ox*a + tw*tb + c0x)
+    int KHt, KWt;         // taps used
+    int KH, KW, kh0, kw0, ts, transposed;   // which weights: (kh0 + ts*th, kw0 + ts*tw) of w[Cout][Cin][KH][KW]
+};
+int64_t taps_split_ws(int M, int C, int ntap);
+void taps_split_launch(const TapsGeom& g, const float* src, const float* w, const OutDesc& dc, int B, int C, int M,
+                       const float* in_scale, const float* in_shift, int in_relu, void* ws, const char* label,
+                       hipStream_t st);
+
 // split-operand weight gradient (conv_wgrad_split.hip): 1x1/pad 0 and 3x3/pad 1, stride 1
 struct WgSplitPlan {
     int M, N, mi, ni, stages, spz, splits;
 };
 WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW);
 void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, float* out, int B, int Cin, int H, int W,
-                        int Cout, int KK, const float* in_scale, const float* in_shift, int in_relu, hipStream_t st);
+                        int Cout, int KK, int stride, const float* in_scale, const float* in_shift, int in_relu,
+                        hipStream_t st);
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int splits,
                                      int accumulate);
 

@@ -74,8 +74,8 @@ static void wgrad_gemm(const WgradPlan& p, const GatherDesc& da, const GatherDes
 // measured at batch 96: the split kernel wins except where the output is tiny and the contraction huge
 // (layer1's 64x64 / 64x256 1x1 convs: staging-bound 64-row tiles), which stay on the fp32 engine
 static bool wgrad_split_ok(int KH, int stride, int pad, int Cout, int Cin) {
-    return stride == 1 && ((KH == 1 && pad == 0) || (KH == 3 && pad == 1)) &&
-           (int64_t)Cout * Cin * KH * KH > 64 * 256;
+    // (1x1/stride 2: the strided 8-dword gather makes the split kernel staging-bound, 315-380 us vs 240-250 us)
+    return ((KH == 1 && pad == 0 && stride == 1) || (KH == 3 && pad == 1)) && (int64_t)Cout * Cin * KH * KH > 64 * 256;
 }
 
 }  // namespace scat
@@ -88,7 +88,7 @@ extern "C" int64_t scat_conv2d_wgrad_ws(int B, int Cin, int H, int W, int Cout, 
     WgradPlan p = wgrad_plan(B, Cin, Cout, KH * KW, OH, OW);
     int64_t need = p.splits > 1 ? (int64_t)p.splits * p.M * p.N * sizeof(float) : 0;
     if (wgrad_split_ok(KH, stride, pad, Cout, Cin)) {            // the math mode may change between this query and the call
-        WgSplitPlan q = wgrad_split_plan(B, Cin, Cout, KH * KW, H * W);
+        WgSplitPlan q = wgrad_split_plan(B, Cin, Cout, KH * KW, OH * OW);
         int64_t n2 = q.splits > 1 ? (int64_t)q.splits * q.M * q.N * sizeof(float) : 0;
         if (n2 > need) need = n2;
     }
@@ -105,13 +105,13 @@ extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int
     SCAT_REQUIRE(!(in_scale && KH == 7), SCAT_E_SHAPE, "scat_conv2d_wgrad: fused input transform not built for 7x7");
     if (!in_scale) in_relu = 0;
     if (math_mode() == 1 && wgrad_split_ok(KH, stride, pad, Cout, Cin)) {
-        const WgSplitPlan q = wgrad_split_plan(B, Cin, Cout, KH * KW, H * W);
+        const WgSplitPlan q = wgrad_split_plan(B, Cin, Cout, KH * KW, OH * OW);
         const int64_t need2 = q.splits > 1 ? (int64_t)q.splits * q.M * q.N * sizeof(float) : 0;
         SCAT_REQUIRE(ws_bytes >= need2 && (need2 == 0 || ws), SCAT_E_WORKSPACE,
                      "scat_conv2d_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need2);
         hipStream_t st2 = (hipStream_t)stream;
-        wgrad_split_launch(q, dy, x, q.splits > 1 ? (float*)ws : dw, B, Cin, H, W, Cout, KH * KW, in_scale, in_shift,
-                           in_relu, st2);
+        wgrad_split_launch(q, dy, x, q.splits > 1 ? (float*)ws : dw, B, Cin, H, W, Cout, KH * KW, stride, in_scale,
+                           in_shift, in_relu, st2);
         SCAT_LAUNCH_CHECK("scat_conv2d_wgrad");
         if (q.splits > 1) {
             int64_t n = (int64_t)q.M * q.N;

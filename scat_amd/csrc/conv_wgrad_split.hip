@@ -21,8 +21,10 @@ struct WgDesc {
     const float* scale;   // optional fused input transform on x, per Cin
     const float* shift;
     int relu;
-    int Cout, Cin, H, W, HW;
-    int NO;               // octets per image = ceil(HW / 8)
+    int Cout, Cin, H, W, HW;   // x plane
+    int OW, OHW;          // dy plane (== x plane for stride 1)
+    int stride, pad;
+    int NO;               // octets per image = ceil(OHW / 8)
     int U;                // octets in total = B * NO
     int N;                // columns = Cin * KK
     int spz;              // stages (2 octets each) per split-K slice
@@ -50,7 +52,8 @@ __device__ __forceinline__ void load8(__amdgpu_buffer_rsrc_t rs, int off, uint32
     for (int q = 0; q < 4; ++q) { v[q] = __uint_as_float(t0[q]); v[4 + q] = __uint_as_float(t1[q]); }
 }
 
-template <int KK, int MI, int NI, bool TF>
+// S2: stride-2 convolution — the 8 pixels of an octet are 8 strided source pixels, fetched as 8 dwords
+template <int KK, int MI, int NI, bool TF, bool S2>
 __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
     constexpr int OSA = BM + 8, OSB = BN + 8;          // u32x4 per (plane, octet) slab; +128 B keeps the two octets of
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc
     } else {
         ci = b_ok ? col : 0;
     }
+    if (S2 && KK == 1) { kh = 0; kw = 0; }             // (the stride-1 path folds pad 1 into kh - 1, kw - 1)
     const int bshift = (kh - 1) * d.W + (kw - 1);
     float bsc = 1.f, bsh = 0.f;
     if (TF && b_ok) { bsc = d.scale[ci]; bsh = d.shift[ci]; }
@@ -99,16 +103,16 @@ __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc
         const uint32_t uu = in ? (uint32_t)u : 0u;
         const uint32_t n = d.dNO.div(uu);
         const int r0 = 8 * (int)(uu - n * (uint32_t)d.NO);
-        const int cnt = in ? min(8, d.HW - r0) : 0;
+        const int cnt = in ? min(8, d.OHW - r0) : 0;
         const uint32_t live = (1u << cnt) - 1u;
         // A: dy[n][arow][r0 .. r0+7]
         {
-            const int off = (a_ok && cnt > 0) ? (((int)n * d.Cout + arow) * d.HW + r0) * 4 : OOB;
+            const int off = (a_ok && cnt > 0) ? (((int)n * d.Cout + arow) * d.OHW + r0) * 4 : OOB;
             load8(rsa, off, a_ok ? live : 0u, d.ndy, araw[Q]);
             amask[Q] = a_ok ? live : 0u;
         }
         // B: x[n][ci][r0 + shift .. +7], per-pixel padding mask
-        {
+        if constexpr (!S2) {
             uint32_t m = live;
             if (KK == 9) {
                 const int y0 = (int)d.dW.div((uint32_t)r0), x0 = r0 - y0 * d.W;
@@ -127,6 +131,21 @@ __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc
             m = b_ok ? m : 0u;
             const int off = m ? (((int)n * d.Cin + ci) * d.HW + r0 + bshift) * 4 : OOB;
             load8(rsb, off, m, d.nx, braw[Q]);
+            bmask[Q] = m;
+        } else {
+            // pixel e of the octet is output pixel (oy, ox): source (2*oy + kh - pad, 2*ox + kw - pad)
+            int oy = (int)d.dW.div((uint32_t)r0), ox = r0 - oy * d.OW;     // dW divides by OW here
+            const int base = ((int)n * d.Cin + ci) * d.HW;
+            uint32_t m = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int sy = d.stride * oy + kh - d.pad, sx = d.stride * ox + kw - d.pad;
+                const bool ok = b_ok && ((live >> e) & 1u) && (unsigned)sy < (unsigned)d.H && (unsigned)sx < (unsigned)d.W;
+                braw[Q][e] = __uint_as_float(
+                    __builtin_amdgcn_raw_buffer_load_b32(rsb, ok ? (base + sy * d.W + sx) * 4 : OOB, 0, 0));
+                m |= (ok ? 1u : 0u) << e;
+                if (++ox == d.OW) { ox = 0; ++oy; }
+            }
             bmask[Q] = m;
         }
     };
@@ -208,20 +227,21 @@ __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc
     store_tile<MI, NI, BM, BN, 2, 2>(acc, dc, d.Cout, d.N, i0, j0, z);
 }
 
-template <int KK, int MI, int NI, bool TF>
+template <int KK, int MI, int NI, bool TF, bool S2>
 static void launch_wg(const WgDesc& d, const OutDesc& dc, int splits, hipStream_t st) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
     const int mt = cdiv(d.Cout, BM), nt = cdiv(d.N, BN);
     constexpr size_t lds_bytes = (size_t)2 * 6 * (BM + 8 + BN + 8) * 16;
-    hipLaunchKernelGGL((wgrad_split_kernel<KK, MI, NI, TF>), dim3(mt * nt, 1, splits), dim3(NT), lds_bytes, st, d, dc);
+    hipLaunchKernelGGL((wgrad_split_kernel<KK, MI, NI, TF, S2>), dim3(mt * nt, 1, splits), dim3(NT), lds_bytes, st, d,
+                       dc);
 }
 
-template <int KK, bool TF>
+template <int KK, bool TF, bool S2>
 static void launch_wg_tile(int mi, int ni, const WgDesc& d, const OutDesc& dc, int splits, hipStream_t st) {
-    if (mi == 2 && ni == 2) launch_wg<KK, 2, 2, TF>(d, dc, splits, st);
-    else if (mi == 2) launch_wg<KK, 2, 1, TF>(d, dc, splits, st);
-    else if (ni == 2) launch_wg<KK, 1, 2, TF>(d, dc, splits, st);
-    else launch_wg<KK, 1, 1, TF>(d, dc, splits, st);
+    if (mi == 2 && ni == 2) launch_wg<KK, 2, 2, TF, S2>(d, dc, splits, st);
+    else if (mi == 2) launch_wg<KK, 2, 1, TF, S2>(d, dc, splits, st);
+    else if (ni == 2) launch_wg<KK, 1, 2, TF, S2>(d, dc, splits, st);
+    else launch_wg<KK, 1, 1, TF, S2>(d, dc, splits, st);
 }
 
 WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW) {
@@ -244,24 +264,35 @@ WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW) {
 }
 
 void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, float* out, int B, int Cin, int H, int W,
-                        int Cout, int KK, const float* in_scale, const float* in_shift, int in_relu, hipStream_t st) {
+                        int Cout, int KK, int stride, const float* in_scale, const float* in_shift, int in_relu,
+                        hipStream_t st) {
     WgDesc d{};
+    const int pad = KK == 9 ? 1 : 0, k = KK == 9 ? 3 : 1;
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
     d.dy = dy; d.x = x; d.scale = in_scale; d.shift = in_shift; d.relu = in_scale ? in_relu : 0;
-    d.Cout = Cout; d.Cin = Cin; d.H = H; d.W = W; d.HW = H * W;
-    d.NO = (d.HW + 7) / 8; d.U = B * d.NO; d.N = p.N; d.spz = p.spz;
-    d.dNO = FastDiv::make(d.NO); d.dW = FastDiv::make(W); d.dKK = FastDiv::make(KK);
-    d.ndy = (int64_t)B * Cout * d.HW; d.nx = (int64_t)B * Cin * d.HW;
+    d.Cout = Cout; d.Cin = Cin; d.H = H; d.W = W; d.HW = H * W; d.OW = OW; d.OHW = OH * OW; d.stride = stride; d.pad = pad;
+    d.NO = (d.OHW + 7) / 8; d.U = B * d.NO; d.N = p.N; d.spz = p.spz;
+    d.dNO = FastDiv::make(d.NO); d.dW = FastDiv::make(OW); d.dKK = FastDiv::make(KK);
+    d.ndy = (int64_t)B * Cout * d.OHW; d.nx = (int64_t)B * Cin * d.HW;
     OutDesc dc{};
     dc.p = out; dc.mode = 0; dc.si = p.N; dc.sj = 1; dc.sz = (int64_t)p.M * p.N; dc.I = p.M; dc.J = p.N;
     dc.n = (int64_t)p.M * p.N;
-    set_kernel_label("wgrad%s_split_%dx%dx16%s_split%d", KK == 9 ? "3x3" : "1x1", 64 * p.mi, 64 * p.ni,
-                     in_scale ? "_tf" : "", p.splits);
-    if (KK == 9) {
-        if (in_scale) launch_wg_tile<9, true>(p.mi, p.ni, d, dc, p.splits, st);
-        else launch_wg_tile<9, false>(p.mi, p.ni, d, dc, p.splits, st);
+    set_kernel_label("wgrad%s%s_split_%dx%dx16%s_split%d", KK == 9 ? "3x3" : "1x1", stride == 2 ? "_s2" : "", 64 * p.mi,
+                     64 * p.ni, in_scale ? "_tf" : "", p.splits);
+    if (stride == 2) {
+        if (KK == 9) {
+            if (in_scale) launch_wg_tile<9, true, true>(p.mi, p.ni, d, dc, p.splits, st);
+            else launch_wg_tile<9, false, true>(p.mi, p.ni, d, dc, p.splits, st);
+        } else {
+            if (in_scale) launch_wg_tile<1, true, true>(p.mi, p.ni, d, dc, p.splits, st);
+            else launch_wg_tile<1, false, true>(p.mi, p.ni, d, dc, p.splits, st);
+        }
+    } else if (KK == 9) {
+        if (in_scale) launch_wg_tile<9, true, false>(p.mi, p.ni, d, dc, p.splits, st);
+        else launch_wg_tile<9, false, false>(p.mi, p.ni, d, dc, p.splits, st);
     } else {
-        if (in_scale) launch_wg_tile<1, true>(p.mi, p.ni, d, dc, p.splits, st);
-        else launch_wg_tile<1, false>(p.mi, p.ni, d, dc, p.splits, st);
+        if (in_scale) launch_wg_tile<1, true, false>(p.mi, p.ni, d, dc, p.splits, st);
+        else launch_wg_tile<1, false, false>(p.mi, p.ni, d, dc, p.splits, st);
     }
 }
 

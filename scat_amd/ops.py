@@ -107,6 +107,13 @@ def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, b
         _prof(2.0 * B * OH * OW * Cout * Cin, lib().scat_conv1x1_s1, _p(x), _p(w), _p(y), B, Cin, H * W, Cout, 0,
               _p(bias), _p(in_scale), _p(in_shift), int(in_relu), 0, _p(ws), ws.numel(), _stream())
         return y
+    if (stride == 2 and KH in (1, 3) and KW == KH and Cin % 16 == 0 and lib().scat_get_math_mode() == 1
+            and os.environ.get("SCAT_S2_SPLIT", "1") != "0"):
+        ws = workspace(lib().scat_conv2d_fwd_split_ws(Cout, Cin, KH, KW), x.device, "wt")
+        _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_fwd_split, _p(x), _p(w), _p(bias), _p(y), B,
+              Cin, H, W, Cout, KH, KW, stride, pad, _p(in_scale), _p(in_shift), int(in_relu), _p(ws), ws.numel(),
+              _stream())
+        return y
     if _halo_ok(KH, KW, stride, pad, Cin, W) and bias is None:
         ws = workspace(lib().scat_conv3x3_s1_ws(Cout, Cin), x.device, "wt")
         _prof(2.0 * B * OH * OW * Cout * Cin * 9, lib().scat_conv3x3_s1, _p(x), _p(w), _p(y), B, Cin, H, W, Cout, 0,

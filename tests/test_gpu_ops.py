@@ -99,13 +99,17 @@ def test_conv_fused_input_transform(ops):
 @pytest.mark.parametrize("H,W", [(13, 9), (8, 14), (7, 7)])
 def test_dgrad_s2_odd_sizes(ops, H, W):
     """parity classes with ragged class grids (odd heights/widths)"""
-    for k, p in ((3, 1), (1, 0)):
-        x = t(50, "x", (2, 12, H, W)).requires_grad_(True)
-        w = t(51, "w", (20, 12, k, k), std=0.2).requires_grad_(True)
-        y = F.conv2d(x.double(), w.double(), stride=2, padding=p)
-        dy = t(52, "dy", tuple(y.shape))
-        (dx_ref,) = torch.autograd.grad(y, x, dy.double())
-        assert rel_err(ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 2, p), dx_ref) < 2e-5
+    for cout in (20, 48):       # 48: multiple of 16 -> the split-operand taps kernel; 20 -> the fp32 engine
+        for k, p in ((3, 1), (1, 0)):
+            x = t(50, "x", (2, 12, H, W)).requires_grad_(True)
+            w = t(51, "w", (cout, 12, k, k), std=0.2).requires_grad_(True)
+            y = F.conv2d(x.double(), w.double(), stride=2, padding=p)
+            dy = t(52, "dy", tuple(y.shape))
+            (dx_ref,) = torch.autograd.grad(y, x, dy.double())
+            assert rel_err(ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 2, p), dx_ref) < 2e-5
+            base = g(t(53, "acc", tuple(x.shape)))
+            got = ops.conv2d_dgrad_w(g(dy), g(w.detach()), tuple(x.shape), 2, p, out=base.clone(), accumulate=True)
+            assert rel_err(got, dx_ref + base.cpu().double()) < 2e-5
 
 
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 20, 72, 9, 13), (1, 16, 200, 5, 63), (3, 36, 64, 7, 7),
@@ -225,6 +229,45 @@ def test_wgrad_stride1(ops, math_mode, math, B, cin, cout, H, W, k):
         got = ops.conv2d_wgrad(g(dy), g(x), w_shape, 1, k // 2, *((g(sc), g(sh), True) if tf else ()))
         # (outputs of <= 64x256 weights stay on the fp32 engine in either mode)
         assert ("_split_" in ops.lib().scat_last_kernel().decode()) == (bool(math) and cout * cin * k * k > 64 * 256)
+        assert rel_err(got, ref) < 2e-5, tf
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,k", [(2, 32, 72, 9, 13, 3), (3, 48, 64, 7, 7, 3), (2, 64, 136, 30, 5, 1),
+                                               (4, 16, 40, 14, 14, 3), (1, 80, 200, 11, 6, 1)])
+def test_conv_stride2_split(ops, B, cin, cout, H, W, k):
+    """stride-2 forward on the taps kernel (contraction ordered tap-major): odd and even planes, channel counts that
+    are odd multiples of 16, ragged tiles, bias, fused input transform (padding must stay zero after it)."""
+    assert ops.get_math_mode() == 1
+    x = t(95, "x", (B, cin, H, W))
+    w = t(96, "w", (cout, cin, k, k), std=(2.0 / (cin * k * k)) ** 0.5)
+    bias = t(97, "b", (cout,))
+    y = F.conv2d(x.double(), w.double(), bias.double(), stride=2, padding=k // 2)
+    yg = ops.conv2d_fwd(g(x), g(w), 2, k // 2, bias=g(bias))
+    assert "_split_" in ops.lib().scat_last_kernel().decode()
+    assert rel_err(yg, y) < 2e-5
+    sc = torch.from_numpy(synth.uniform(98, "sc", (cin,), 0.5, 1.5))
+    sh = torch.from_numpy(synth.uniform(99, "sh", (cin,), 0.1, 0.6))     # positive shift: relu(0*s+t) != 0 on padding
+    a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    yt = F.conv2d(a.double(), w.double(), stride=2, padding=k // 2)
+    assert rel_err(ops.conv2d_fwd(g(x), g(w), 2, k // 2, g(sc), g(sh), True), yt) < 2e-5
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,k", [(2, 20, 136, 9, 13, 3), (3, 36, 64, 7, 7, 3), (2, 144, 136, 8, 14, 1),
+                                               (5, 128, 128, 14, 14, 3), (1, 96, 208, 5, 63, 1)])
+def test_wgrad_stride2_split(ops, B, cin, cout, H, W, k):
+    """weight gradient of the stride-2 convolutions on the split-operand kernel (strided source gather)."""
+    assert ops.get_math_mode() == 1
+    x = t(84, "x", (B, cin, H, W))
+    w_shape = (cout, cin, k, k)
+    OH, OW = ops.conv_out_hw(H, W, k, 2, k // 2)
+    dy = t(85, "dy", (B, cout, OH, OW))
+    sc = torch.from_numpy(synth.uniform(86, "sc", (cin,), 0.5, 1.5))
+    sh = torch.from_numpy(synth.uniform(87, "sh", (cin,), 0.1, 0.6))
+    for tf in (False, True):
+        a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if tf else x
+        ref = torch.nn.grad.conv2d_weight(a.double(), w_shape, dy.double(), stride=2, padding=k // 2)
+        got = ops.conv2d_wgrad(g(dy), g(x), w_shape, 2, k // 2, *((g(sc), g(sh), True) if tf else ()))
+        assert ("_s2_split_" in ops.lib().scat_last_kernel().decode()) == (k == 3)   # 1x1/s2 stays on the fp32 engine
         assert rel_err(got, ref) < 2e-5, tf
 
 
