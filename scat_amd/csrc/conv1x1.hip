@@ -31,6 +31,7 @@ struct PwDesc {
     // (oy*a + th*tb + c0y, ox*a + tw*tb + c0x); a 1x1/stride-1 conv has ntap = 1, a = 1, OHW = HW
     int ntap, KWt, a, tb, c0y, c0x, H, W, OW, OHW;
     FastDiv dOHW, dOW;
+    int variant;          // SCAT_TUNE pass-through for kernel-variant experiments
 };
 
 constexpr int PW_KS = 32;     // channels per LDS stage (two 16-channel sub-chunks)
@@ -304,6 +305,46 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
         }
     };
 
+    // the same work in 2*NI slices, one per MFMA group of a stage: slice i splits PP element pairs and writes an
+    // octet's three fragments once its fourth pair is done (fragments live in shi/smid/slo across slices)
+    constexpr int PP = NIT * 4 / (2 * NI) > 0 ? NIT * 4 / (2 * NI) : 1;
+    uint32_t shi[2], smid[2], slo[2];                  // one half octet: written as 8 bytes per plane
+    auto store_slice = [&](int st, u32x4* dst, auto set_tag, auto idx_tag) {
+        constexpr int Q = decltype(set_tag)::value, IDX = decltype(idx_tag)::value;
+        const int tap = st / nsc, c0 = (st - tap * nsc) * PW_KS;
+        const bool live = (pmask >> (tap < 9 ? tap : 9)) & 1u;
+        static_for<PP>([&](auto j_tag) {
+            constexpr int pp = IDX * PP + decltype(j_tag)::value;
+            if constexpr (pp < NIT * 4) {
+            constexpr int r = pp >> 2, q = pp & 3;
+            float x[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int m = 2 * q + u;
+                float t = bst[Q][r][m];
+                if constexpr (TF) {
+                    const int c = c0 + 8 * (g0u + r * (NT / BN)) + m;
+                    const int cc = c < d.C ? c : 0;
+                    t = fmaf(t, d.scale[cc], d.shift[cc]);
+                    t = d.relu ? fmaxf(t, 0.f) : t;
+                    t = live ? t : 0.f;
+                }
+                x[u] = t;
+            }
+            uint32_t h, mm, l;
+            split3(x[0], x[1], h, mm, l);
+            shi[q & 1] = h; smid[q & 1] = mm; slo[q & 1] = l;
+            if constexpr ((q & 1) == 1) {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const int g = g0 + r * (NT / BN);
+                u32x2* p = (u32x2*)(dst + (0 * 4 + g) * BN + pcol) + (q >> 1);
+                p[0] = u32x2{shi[0], shi[1]};
+                p[(size_t)4 * BN * 2] = u32x2{smid[0], smid[1]};
+                p[(size_t)8 * BN * 2] = u32x2{slo[0], slo[1]};
+            }
+            }
+        });
+    };
     // ---- weights: pre-split planes ws[chunk][plane][row][16 bf16]; lane (row, h) takes 16 bytes per plane
     const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(d.w, d.nw);
     const int row = i0 + wm * 32 + l31;
@@ -351,20 +392,19 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
         const u32x4* bcur = Bs(CUR);
         u32x4* bnext = Bs(CUR ^ 1);
         load_b(s + 2, std::integral_constant<int, CUR>{});
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            load_a(areg[t ^ 1], 2 * s + t + 1);        // next sub-chunk's weights, one sub-chunk ahead
-#pragma unroll
-            for (int b = 0; b < NI; ++b) {
-                const int fcur = (t * NI + b) & 1, fnxt = fcur ^ 1;
-                if (b + 1 < NI) read_b(bfr[fnxt], bcur, t, b + 1);
-                else if (t == 0) read_b(bfr[fnxt], bcur, 1, 0);
+            // the split of stage s+1 (its data landed a stage ago, its LDS buffer has been free since the last
+            // barrier) rides in the shadow of this stage's MFMAs: one slice per MFMA group
+            static_for<2 * NI>([&](auto i_tag) {
+                constexpr int I = decltype(i_tag)::value, t = I / NI, b = I % NI;
+                if constexpr (b == 0) load_a(areg[t ^ 1], 2 * s + t + 1);
+                constexpr int fcur = I & 1, fnxt = fcur ^ 1;
+                if constexpr (b + 1 < NI) read_b(bfr[fnxt], bcur, t, b + 1);
+                else if constexpr (t == 0) read_b(bfr[fnxt], bcur, 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                store_slice(s + 1, bnext, std::integral_constant<int, CUR ^ 1>{}, i_tag);
                 acc[0][b] = mfma_split(areg[t], bfr[fcur], acc[0][b]);
                 __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        store_b(s + 1, bnext, std::integral_constant<int, CUR ^ 1>{});
+            });
         __syncthreads();
         read_b(bfr[0], bnext, 0, 0);
     };
@@ -446,6 +486,7 @@ void taps_split_launch(const TapsGeom& g, const float* src, const float* w, cons
     d.ntap = g.KHt * g.KWt; d.KWt = g.KWt; d.a = g.a; d.tb = g.tb; d.c0y = g.c0y; d.c0x = g.c0x; d.H = g.H; d.W = g.W;
     d.OW = g.OW; d.OHW = g.OH * g.OW; d.dOHW = FastDiv::make(d.OHW); d.dOW = FastDiv::make(g.OW);
     d.nsrc = (int64_t)B * C * d.HW;
+    d.variant = tuning();
     const int64_t nel = (int64_t)d.ntap * M * ((C + 15) / 16 * 16);
     const int rblocks = (int)((nel + 255) / 256 < 2048 ? (nel + 255) / 256 : 2048);
     hipLaunchKernelGGL(w_taps_split_kernel, dim3(rblocks), dim3(256), 0, st, w, (uint16_t*)ws, M, C, g.transposed, g.KH,
@@ -532,6 +573,7 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
     d.ntap = 1; d.KWt = 1; d.a = 1; d.tb = 1; d.c0y = 0; d.c0x = 0; d.H = 1; d.W = HW; d.OW = HW; d.OHW = HW;
     d.dOHW = FastDiv::make(HW); d.dOW = FastDiv::make(HW);
     d.nsrc = (int64_t)B * C * HW; d.nw = (int64_t)M * C;
+    d.variant = tuning();
     OutDesc dc{};
     dc.p = dst; dc.mode = 1; dc.I = M; dc.J = d.npix; dc.C = M; dc.HW = HW; dc.dHW = FastDiv::make(HW);
     dc.bias = bias; dc.bias_mode = bias ? 1 : 0; dc.accumulate = accumulate; dc.n = (int64_t)B * M * HW;
