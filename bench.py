@@ -81,6 +81,23 @@ def cpu_baseline(batch=32, steps=5):
                       f"{dt:.1f} s of CPU work, torch {torch.__version__} CPU"}
 
 
+def instantiation_of(label):
+    """kernel label (scat_last_kernel) -> the template instantiation it launches, as tools/traffic_json.py names it"""
+    import re
+    tf = "t" if label.endswith("_tf") or "_tf_" in label else "f"
+    m = re.search(r"_split_(\d+)x(\d+)x32", label)
+    if m:       # pointwise / taps kernel: WM = rows / 32
+        return f"conv1x1_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf}>"
+    m = re.match(r"conv3x3_split_(\d+)x(\d+)x16", label)
+    if m:
+        return f"conv3x3_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf}>"
+    m = re.match(r"wgrad(1x1|3x3)(_s2)?_split_(\d+)x(\d+)x16", label)
+    if m:
+        return (f"wgrad_split_kernel<{9 if m.group(1) == '3x3' else 1},{int(m.group(3)) // 64},{int(m.group(4)) // 64},"
+                f"{tf},{'t' if m.group(2) else 'f'}>")
+    return label
+
+
 def dominant_kernel_roofline(ts, x, lab):
     """One extra instrumented step (outside the timed region): HIP events around every launch of the
     contraction engine, grouped by kernel instantiation; report the one with the most total time."""
@@ -113,7 +130,7 @@ def dominant_kernel_roofline(ts, x, lab):
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-            traffic = json.load(fh).get(name, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(fh).get(instantiation_of(name), {}).get("hbm_bytes_per_launch")
     except OSError:
         pass
     # kernels whose label says "split" form each fp32 product from six bf16 MFMA terms: their
