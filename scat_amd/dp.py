@@ -77,6 +77,52 @@ class GradBuckets:
         if backbone is not None:
             backbone._grad_sink = self
         self.model = model
+        self._auto = False
+        self._armed = False
+
+    # ---- unattended mode: the unmodified train.py never calls begin_backbone()/finish() itself
+    def enable_auto(self):
+        """Drive the buckets from autograd alone (SURVEY §8(e) 'train.py compatibility'): every parameter gets a
+        post-accumulate hook; a bucket is all-reduced as soon as all of its parameters have their gradient; the
+        compute stream is made to wait for the collectives by a callback at the end of the backward pass, so the
+        ``optimizer.step()`` that follows sees averaged gradients.  Parameters the fused backbone backward fills
+        directly (they never pass through AccumulateGrad) keep using ready()/adopt()."""
+        if self._auto:
+            return
+        self._auto = True
+        self._bucket_of_param = {}
+        self._need = {}
+        for b, (a, e) in self.ranges.items():
+            members = [p for p, (off, _) in self.slot.items() if a <= off < e]
+            self._need[b] = len(members)
+            for p in members:
+                self._bucket_of_param[p] = b
+        self._have = {b: 0 for b in self.ranges}
+        for p in self.slot:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _arm(self):
+        if self._auto and not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+
+    def _on_grad(self, p):
+        self._arm()
+        v = self.view_for(p)
+        if p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)
+            p.grad = v
+        b = self._bucket_of_param[p]
+        self._have[b] += 1
+        if self._have[b] == self._need[b]:
+            self._allreduce(self.grad_slice(b))
+            if b == "head":
+                self._head_sent = True
+
+    def _end_of_backward(self):
+        self._armed = False
+        self._have = {b: 0 for b in self.ranges}
+        self.finish()
 
     # ---- views
     def view_for(self, p):
@@ -98,12 +144,23 @@ class GradBuckets:
                 return
             except RuntimeError:
                 self._avg_ok = False             # older RCCL without AVG: sum, then scale
-        if True:                # gloo (CPU tests) / fallback: SUM then 1/N
-            self._pending.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), t))
+        if t.is_cuda and backend != "nccl":
+            # gloo with device tensors (rehearsing N ranks on one GPU): its asynchronous device path does not order
+            # itself against HIP streams the way RCCL does (measured: buckets reduced before their last kernel had
+            # written them) — reduce synchronously; this is a test vehicle, not a performance path
+            torch.cuda.current_stream(t.device).synchronize()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+            t.mul_(1.0 / self.world)
+            return
+        # gloo on host tensors (CPU tests) / RCCL without AVG: SUM, scaled by 1/N in finish()
+        self._pending.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), t))
 
     def begin_backbone(self):
         """Called at the top of the backbone backward: head gradients are final by then (every head node is
         nearer the loss than the backbone).  Gather them into the flat buffer and reduce them first."""
+        self._arm()
+        if self._auto and self._head_sent:
+            return          # the hooks already reduced the head bucket
         dst, src = [], []
         for p in self.head_params:
             v = self.view_for(p)
@@ -170,3 +227,21 @@ def init_distributed():
             kw["device_id"] = torch.device("cuda", local)
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local, world
+
+
+def auto_attach(model):
+    """Called from the model's forward: under ``torch.distributed.run`` (WORLD_SIZE > 1) the first training-mode
+    forward creates the flat buckets in unattended mode, so the reference's train.py (plain ``optim.Adam`` over
+    ``net.parameters()``, ``loss.backward(); optimizer.step()``) trains data-parallel without modification.
+    A model already owned by ``scat_amd.trainer.TrainStep`` (or attached before) is left alone."""
+    import os
+
+    if getattr(model, "_dp_buckets", None) is not None or not model.training:
+        return
+    if getattr(getattr(model, "main_encoder", None), "_grad_sink", None) is not None:
+        return
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return
+    init_distributed()
+    model._dp_buckets = GradBuckets(model)
+    model._dp_buckets.enable_auto()

@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from .. import nn as snn
 from .. import ops
+from ..dp import auto_attach
 from . import hrnet, resnet, vision_transformer, vision_transformer_attn, vit
 
 
@@ -127,6 +128,7 @@ class EncoderTransformerHRNet(nn.Module):
         self._midx_cache = {}
 
     def forward(self, main_input):
+        auto_attach(self)
         main_feat = self.main_encoder(main_input)                               # [B,128,56,56]
         B = main_feat.size(0)
         feat = self.conv1x1_channel_reduction(main_feat.view(B, 512, 28, 28))   # legal only at 224x224
@@ -168,6 +170,7 @@ class EncoderTransformerCoarse(nn.Module):
     _draw_mask = None   # bound below (same python-random draw as EncoderTransformer)
 
     def forward(self, main_input):
+        auto_attach(self)
         main_feat, x1, x2, x3, x4 = self.main_encoder(main_input)
         feat_visual = self.conv1x1_channel_reduction(x2)
         B = feat_visual.size(0)
@@ -236,6 +239,7 @@ class EncoderTransformer(nn.Module):
         return t
 
     def forward(self, main_input):
+        auto_attach(self)   # WORLD_SIZE > 1: data-parallel gradient averaging without touching train.py
         main_feat, x1, x2, x3, x4 = self.main_encoder(main_input)
         feat_visual = self.conv1x1_channel_reduction(x2)                      # [B,21,28,28]
         B = feat_visual.size(0)

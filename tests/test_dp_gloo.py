@@ -94,6 +94,56 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _worker_auto(rank, world, port, out):
+    """unattended mode: nothing but forward / backward / optimizer.step(), like the reference's train.py"""
+    import torch.distributed as dist
+
+    from scat_amd import dp
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank), SCAT_DIST_BACKEND="gloo")
+    torch.manual_seed(0)
+    net, ref = _Tiny(), _Tiny()
+    ref.load_state_dict(net.state_dict())
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)          # built BEFORE the buckets exist, as train.py does
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    for step in range(3):
+        dp.auto_attach(net)                                    # what EncoderTransformer.forward does
+        torch.manual_seed(100 * step + rank)
+        x, y = torch.randn(8, 6), torch.randn(8, 3)
+        opt.zero_grad()
+        (net(x) - y).square().mean().backward()
+        ropt.zero_grad()
+        (ref(x) - y).square().mean().backward()
+        for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            g = q.grad.clone()
+            dist.all_reduce(g)
+            g /= world
+            q.grad = g                                         # the reference, averaged by hand
+            assert torch.allclose(p.grad, g, atol=1e-7), (step, n)
+        opt.step()
+        ropt.step()
+        for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            assert torch.allclose(p, q, atol=1e-7), (step, n)
+    assert net._dp_buckets.world == world
+    out.put((rank, 0.0))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_unattended():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_auto, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(100)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in (q.get(timeout=5) for _ in range(2))) == [0, 1]
+
+
 @pytest.mark.timeout(120)
 def test_two_rank_buckets():
     ctx = mp.get_context("spawn")
