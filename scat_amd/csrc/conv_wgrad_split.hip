@@ -253,7 +253,11 @@ WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW) {
     const int NO = (HW + 7) / 8;
     p.stages = (B * NO + 1) / 2;
     const int tiles = cdiv(p.M, 64 * p.mi) * cdiv(p.N, 64 * p.ni);
-    int s = cdiv(1536, tiles);                        // ~6 workgroups per CU over the whole grid
+    // measured at batch 96 (SCAT_WG_TARGET sweeps): ~2 workgroups per CU for 1x1 (slab traffic and the reduce
+    // launch grow with the split count), ~6 for 3x3 (its staging is VALU-bound, more co-resident waves help)
+    static const int forced = [] { const char* e = getenv("SCAT_WG_TARGET"); return e ? atoi(e) : 0; }();
+    const int target = forced > 0 ? forced : (KK == 1 ? 512 : 1536);
+    int s = cdiv(target, tiles);
     const int smax = p.stages / 24 > 0 ? p.stages / 24 : 1;   // >= 24 stages (384 pixels) per slice
     if (s > smax) s = smax;
     if (s > 512) s = 512;
