@@ -75,7 +75,8 @@ static void wgrad_gemm(const WgradPlan& p, const GatherDesc& da, const GatherDes
 // (layer1's 64x64 / 64x256 1x1 convs: staging-bound 64-row tiles), which stay on the fp32 engine
 static bool wgrad_split_ok(int KH, int stride, int pad, int Cout, int Cin) {
     // (1x1/stride 2: the strided 8-dword gather makes the split kernel staging-bound, 315-380 us vs 240-250 us)
-    return ((KH == 1 && pad == 0 && stride == 1) || (KH == 3 && pad == 1)) && (int64_t)Cout * Cin * KH * KH > 64 * 256;
+    static const int64_t minmn = [] { const char* e = getenv("SCAT_WG_MINMN"); return e ? atoll(e) : 64ll * 256; }();
+    return ((KH == 1 && pad == 0 && stride == 1) || (KH == 3 && pad == 1)) && (int64_t)Cout * Cin * KH * KH > minmn;
 }
 
 }  // namespace scat

@@ -260,7 +260,7 @@ WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW) {
     int s = cdiv(target, tiles);
     const int smax = p.stages / 24 > 0 ? p.stages / 24 : 1;   // >= 24 stages (384 pixels) per slice
     if (s > smax) s = smax;
-    if (s > 512) s = 512;
+    if (s > 2048) s = 2048;
     if (s < 1) s = 1;
     p.spz = cdiv(p.stages, s);
     p.splits = cdiv(p.stages, p.spz);
