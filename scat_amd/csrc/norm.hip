@@ -115,7 +115,8 @@ template <int V>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const float* __restrict__ res, int relu,
-                                                       float* __restrict__ y, int64_t nvec, FastDiv dHWv, FastDiv dC) {
+                                                       float* __restrict__ y, uint8_t* __restrict__ mask,
+                                                       int64_t nvec, FastDiv dHWv, FastDiv dC) {
     for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < nvec; e += gridDim.x * 256ll) {
         const uint32_t row = dHWv.div((uint32_t)e);
         const int c = (int)(row - dC.div(row) * dC.d);
@@ -126,6 +127,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             if (res) { float4 r = ((const float4*)res)[e]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             ((float4*)y)[e] = v;
+            // sign bits of the output, one byte per float4: what the backward needs of y (32x fewer bytes)
+            if (mask) mask[e] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
         } else {
             float v = fmaf(x[e], sc, sh);
             if (res) v += res[e];
@@ -138,14 +141,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // ---------------------------------------------------------------- BN backward
 
 __device__ __forceinline__ float bn_mask(float dy, float x, float yv, bool has_y, int relu, float sc, float sh) {
-    if (has_y) return yv > 0.f ? dy : 0.f;
+    if (has_y) return yv > 0.f ? dy : 0.f;      // (a sign-mask bit is passed as yv = 1 / 0)
     if (relu) return fmaf(x, sc, sh) > 0.f ? dy : 0.f;
     return dy;
 }
 
 template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                            const float* __restrict__ yout, int relu,
+                                                            const float* __restrict__ yout,
+                                                            const uint8_t* __restrict__ ymask, int relu,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ mean,
@@ -154,7 +158,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const int c = blockIdx.x, s = blockIdx.y;
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
     const int nimg = (B - s + S - 1) / S, hwv = HW / V;
-    const bool has_y = yout != nullptr;
+    const bool has_m = V == 4 && ymask != nullptr;
+    const bool has_y = yout != nullptr || has_m;
     double s1 = 0, s2 = 0;
     for (int idx = threadIdx.x; idx < nimg * hwv; idx += 256) {
         const int nl = (int)dHWv.div((uint32_t)idx), i = idx - nl * hwv;
@@ -163,7 +168,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         if (V == 4) {
             float4 t = *(const float4*)(x + off); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
             t = *(const float4*)(dy + off); gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
-            if (has_y) { t = *(const float4*)(yout + off); yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w; }
+            if (has_m) {
+                const uint32_t m = ymask[off >> 2];
+                yv[0] = (float)(m & 1u); yv[1] = (float)((m >> 1) & 1u); yv[2] = (float)((m >> 2) & 1u); yv[3] = (float)((m >> 3) & 1u);
+            } else if (has_y) { t = *(const float4*)(yout + off); yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w; }
         } else {
             xv[0] = x[off]; gv[0] = dy[off];
             if (has_y) yv[0] = yout[off];
@@ -202,7 +210,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, i
 // dx may alias dy, dres may alias dy: every element is read before it is written by the same thread
 template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, const float* __restrict__ x,
-                                                           const float* __restrict__ yout, int relu,
+                                                           const float* __restrict__ yout,
+                                                           const uint8_t* __restrict__ ymask, int relu,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ mean,
@@ -211,7 +220,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
                                                            const float* __restrict__ coef, float* dx,
                                                            float* dres, int dres_acc, int64_t nvec, FastDiv dHWv,
                                                            FastDiv dC) {
-    const bool has_y = yout != nullptr;
+    const bool has_m = V == 4 && ymask != nullptr;
+    const bool has_y = yout != nullptr || has_m;
     for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < nvec; e += gridDim.x * 256ll) {
         const uint32_t row = dHWv.div((uint32_t)e);
         const int c = (int)(row - dC.div(row) * dC.d);
@@ -221,7 +231,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
         if (V == 4) {
             float4 t = ((const float4*)x)[e]; xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
             t = ((const float4*)dy)[e]; gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
-            if (has_y) { t = ((const float4*)yout)[e]; yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w; }
+            if (has_m) {
+                const uint32_t m = ymask[e];
+                yv[0] = (float)(m & 1u); yv[1] = (float)((m >> 1) & 1u); yv[2] = (float)((m >> 2) & 1u); yv[3] = (float)((m >> 3) & 1u);
+            } else if (has_y) { t = ((const float4*)yout)[e]; yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w; }
             if (dres && dres_acc) { t = ((const float4*)dres)[e]; rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
         } else {
             xv[0] = x[e]; gv[0] = dy[e];
@@ -364,7 +377,7 @@ extern "C" int scat_bn_eval_fold(const float* gamma, const float* beta, const fl
 }
 
 extern "C" int scat_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, int relu,
-                             float* y, int B, int C, int HW, void* stream) {
+                             float* y, uint8_t* mask_out, int B, int C, int HW, void* stream) {
     SCAT_REQUIRE(x && scale && shift && y, SCAT_E_ARG, "scat_bn_apply: null pointer");
     SCAT_REQUIRE(B > 0 && C > 0 && HW > 0, SCAT_E_SHAPE, "scat_bn_apply: non-positive dimension");
     const int64_t total = (int64_t)B * C * HW;
@@ -374,16 +387,18 @@ extern "C" int scat_bn_apply(const float* x, const float* scale, const float* sh
     if (vec) {
         const int64_t nv = total / 4;
         hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_grid(nv)), dim3(256), 0, st, x, scale, shift, residual, relu, y,
-                           nv, FastDiv::make(HW / 4), FastDiv::make(C));
+                           mask_out, nv, FastDiv::make(HW / 4), FastDiv::make(C));
     } else {
+        SCAT_REQUIRE(!mask_out, SCAT_E_SHAPE, "scat_bn_apply: the sign mask needs HW % 4 == 0 and 16-B aligned tensors");
         hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, x, scale, shift, residual, relu,
-                           y, total, FastDiv::make(HW), FastDiv::make(C));
+                           y, nullptr, total, FastDiv::make(HW), FastDiv::make(C));
     }
     SCAT_LAUNCH_CHECK("scat_bn_apply");
     return SCAT_OK;
 }
 
-extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, int relu, const float* scale,
+extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, const uint8_t* y_mask, int relu,
+                           const float* scale,
                            const float* shift, const float* save_mean, const float* save_invstd, const float* gamma,
                            float* dgamma, float* dbeta, float* dx, float* dres, int dres_accumulate, int B, int C,
                            int HW, void* ws, int64_t ws_bytes, void* stream) {
@@ -399,22 +414,24 @@ extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, 
     SCAT_REQUIRE(fits_i32(total), SCAT_E_SHAPE, "scat_bn_bwd: tensor exceeds 2^31 elements");
     const bool vec = (HW & 3) == 0 &&
                      (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y_out | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
+    SCAT_REQUIRE(!y_mask || vec, SCAT_E_SHAPE, "scat_bn_bwd: the sign mask needs HW % 4 == 0 and 16-B aligned tensors");
+    SCAT_REQUIRE(!(y_mask && y_out), SCAT_E_ARG, "scat_bn_bwd: pass the output OR its sign mask");
     if (vec)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C, S), dim3(256), 0, st, dy, x, y_out, relu, scale, shift,
-                           save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW / 4), part);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C, S), dim3(256), 0, st, dy, x, y_out, y_mask, relu, scale,
+                           shift, save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW / 4), part);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C, S), dim3(256), 0, st, dy, x, y_out, relu, scale, shift,
-                           save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW), part);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C, S), dim3(256), 0, st, dy, x, y_out, nullptr, relu, scale,
+                           shift, save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW), part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
                        (double)B * HW, dgamma, dbeta, coef);
     if (vec) {
         const int64_t nv = total / 4;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(nv)), dim3(256), 0, st, dy, x, y_out, relu, scale,
-                           shift, save_mean, save_invstd, gamma, (const float*)coef, dx, dres, dres_accumulate, nv,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(nv)), dim3(256), 0, st, dy, x, y_out, y_mask, relu,
+                           scale, shift, save_mean, save_invstd, gamma, (const float*)coef, dx, dres, dres_accumulate, nv,
                            FastDiv::make(HW / 4), FastDiv::make(C));
     } else {
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, dy, x, y_out, relu, scale,
-                           shift, save_mean, save_invstd, gamma, (const float*)coef, dx, dres, dres_accumulate, total,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, dy, x, y_out, nullptr, relu,
+                           scale, shift, save_mean, save_invstd, gamma, (const float*)coef, dx, dres, dres_accumulate, total,
                            FastDiv::make(HW), FastDiv::make(C));
     }
     SCAT_LAUNCH_CHECK("scat_bn_bwd");

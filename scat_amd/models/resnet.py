@@ -109,8 +109,11 @@ class _BackboneFn(torch.autograd.Function):
                 else:
                     cd = sd = None
                     res = xin
-                cur = ops.bn_apply(c3, s3.scale, s3.shift, res, True)
-                tape.append((blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, cur))
+                if training:    # the backward wants only the sign of the block output: keep 1 bit per element for it
+                    cur, omask = ops.bn_apply(c3, s3.scale, s3.shift, res, True, want_mask=True)
+                else:
+                    cur, omask = ops.bn_apply(c3, s3.scale, s3.shift, res, True), None
+                tape.append((blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, cur, omask))
             feats.append(cur)
         if _NBT:
             torch._foreach_add_(_NBT, 1)
@@ -177,7 +180,7 @@ class _BackboneFn(torch.autograd.Function):
 
         stage_grads = [dx1, dx2, dx3, dx4]
         # ---- tail: relu(fc1(relu(avgpool(x4))))
-        x4 = tape[-1][-1]
+        x4 = tape[-1][-2]          # (block output; the last entry is its sign mask)
         if dfeat is not None:
             dfc = ops.relu_bwd(dfeat if dfeat.is_contiguous() else dfeat.contiguous(), feat)
             put(net.fc1.weight, ops.linear_wgrad(dfc, pooled, out=gbuf(net.fc1.weight)))
@@ -196,10 +199,10 @@ class _BackboneFn(torch.autograd.Function):
         if ext is not None:
             dcur = ops.axpy(dcur, ext.contiguous(), 1.0, out=dcur)
         for rec in reversed(tape):
-            blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out = rec
+            blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out, omask = rec
             # out = relu(bn3(c3) + res): g = dcur * (out>0) is also the residual branch's gradient
             dc3, dg, db = ops.bn_bwd(dcur, c3, out, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
-                                     gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), dres=dcur)
+                                     gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), dres=dcur, y_mask=omask)
             put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
             g = dcur
             put(blk.conv3.weight, wgrad(dc3, c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True))

@@ -254,24 +254,32 @@ def bn_eval_fold(gamma, beta, running_mean, running_var, eps=1e-5):
     return o[0], o[1]
 
 
-def bn_apply(x, scale, shift, residual=None, relu=False, out=None):
+def bn_apply(x, scale, shift, residual=None, relu=False, out=None, want_mask=False):
+    """want_mask: also return the sign mask of the output (uint8, one byte per 4 elements; None when the plane is not
+    a multiple of 4) — what bn_bwd needs of y, 32x smaller."""
     _chk(x, scale, shift, residual, out)
     B, C, H, W = x.shape
     y = out if out is not None else torch.empty_like(x)
-    lib().scat_bn_apply(_p(x), _p(scale), _p(shift), _p(residual), int(relu), _p(y), B, C, H * W, _stream())
-    return y
+    mask = None
+    if want_mask and (H * W) % 4 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in (x, y, residual)):
+        mask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=x.device)
+    lib().scat_bn_apply(_p(x), _p(scale), _p(shift), _p(residual), int(relu), _p(y), _p(mask), B, C, H * W, _stream())
+    return (y, mask) if want_mask else y
 
 
 def bn_bwd(dy, x, y_out, relu, scale, shift, save_mean, save_invstd, gamma, dgamma=None, dbeta=None, dx=None,
-           dres=None, dres_accumulate=False):
-    """-> (dx, dgamma, dbeta); if dres is given, the masked gradient is written/accumulated there."""
+           dres=None, dres_accumulate=False, y_mask=None):
+    """-> (dx, dgamma, dbeta); if dres is given, the masked gradient is written/accumulated there.  y_mask (from
+    bn_apply(want_mask=True)) replaces y_out."""
+    if y_mask is not None:
+        y_out = None
     _chk(dy, x, y_out, scale, shift, save_mean, save_invstd, gamma, dgamma, dbeta, dx, dres)
     B, C, H, W = x.shape
     dx = dx if dx is not None else torch.empty_like(x)
     dgamma = dgamma if dgamma is not None else torch.empty_like(gamma)
     dbeta = dbeta if dbeta is not None else torch.empty_like(gamma)
     ws = workspace(lib().scat_bn_ws(B, C, H * W), x.device)
-    lib().scat_bn_bwd(_p(dy), _p(x), _p(y_out), int(relu), _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
+    lib().scat_bn_bwd(_p(dy), _p(x), _p(y_out), _p(y_mask), int(relu), _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
                       _p(gamma), _p(dgamma), _p(dbeta), _p(dx), _p(dres), int(dres_accumulate), B, C, H * W, _p(ws),
                       ws.numel(), _stream())
     return dx, dgamma, dbeta

@@ -327,6 +327,28 @@ def test_batchnorm(ops, B, C, H):
     assert rel_err(ops.bn_apply(xg, sc_e, sh_e), ye) < 1e-5
 
 
+def test_batchnorm_sign_mask(ops):
+    """bn_bwd from the 1-bit sign mask of the block output == bn_bwd from the output itself, bit for bit."""
+    B, C, H = 3, 64, 28
+    x, res, dy = (g(t(30 + i, n, (B, C, H, H))) for i, n in enumerate(("x", "res", "dy")))
+    gamma = g(torch.from_numpy(synth.uniform(33, "g", (C,), 0.5, 1.5)))
+    beta = g(t(34, "b", (C,), 0.1))
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, invstd, scale, shift = ops.bn_train_stats(x, gamma, beta, rm, rv)
+    y, mask = ops.bn_apply(x, scale, shift, res, True, want_mask=True)
+    assert mask is not None and mask.dtype == torch.uint8 and mask.numel() == y.numel() // 4
+    bits = ((mask.view(-1, 1) >> torch.arange(4, device=DEV, dtype=torch.uint8)) & 1).bool().view_as(y)
+    assert torch.equal(bits, y > 0)
+    a = ops.bn_bwd(dy, x, y, True, scale, shift, mean, invstd, gamma, dres=torch.empty_like(dy))
+    dres_a = torch.empty_like(dy)
+    a = ops.bn_bwd(dy, x, y, True, scale, shift, mean, invstd, gamma, dres=dres_a)
+    dres_b = torch.empty_like(dy)
+    b = ops.bn_bwd(dy, x, None, True, scale, shift, mean, invstd, gamma, dres=dres_b, y_mask=mask)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert torch.equal(dres_a, dres_b)
+
+
 def test_pools(ops):
     B, C, H = 3, 16, 112
     x = t(24, "x", (B, C, H, H)).requires_grad_(True)
