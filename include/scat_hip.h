@@ -123,6 +123,24 @@ int scat_bn_bwd(const float* dy, const float* x, const float* y_out, const uint8
                 float* dgamma, float* dbeta, float* dx, float* dres, int dres_accumulate, int B, int C, int HW,
                 void* ws, int64_t ws_bytes, void* stream);
 
+/* BatchNorm backward split in two so that its second half never touches memory: this call masks dy IN PLACE
+ * (g = dy * mask; g is also the residual branch's gradient), reduces the per-channel sums and emits
+ * coef3[3*C] = (ca | cb | cc) with  dx = ca*g + cb*x + cc;  the consumers of dx apply that while loading their
+ * operand (scat_conv1x1_s1_bnb, scat_conv1x1_wgrad_bnb).  Needs HW % 4 == 0 and 16-B aligned tensors. */
+int scat_bn_bwd_pre(float* dy_g, const float* x, const float* y_out, const uint8_t* y_mask, int relu, const float* scale,
+                    const float* shift, const float* save_mean, const float* save_invstd, const float* gamma,
+                    float* dgamma, float* dbeta, float* coef3, int B, int C, int HW, void* ws, int64_t ws_bytes,
+                    void* stream);
+/* dx[B,Cin,HW] (+)= w^T . (ca*g + cb*z + cc): data gradient of a 1x1 conv whose output gradient is the BatchNorm
+ * backward above (g, coef3 from scat_bn_bwd_pre; z = the conv's raw output).  ws: scat_conv1x1_s1_ws(Cin, Cout). */
+int scat_conv1x1_s1_bnb(const float* g, const float* z, const float* coef3, const float* w, float* dx, int B, int Cin,
+                        int HW, int Cout, int accumulate, void* ws, int64_t ws_bytes, void* stream);
+/* dw[Cout,Cin] = sum over pixels (ca*g + cb*z + cc)[co] * relu(x*scale+shift)[ci]: the same conv's weight gradient. */
+int64_t scat_conv1x1_wgrad_bnb_ws(int B, int Cin, int HW, int Cout);
+int scat_conv1x1_wgrad_bnb(const float* g, const float* z, const float* coef3, const float* x, float* dw, int B, int Cin,
+                           int HW, int Cout, const float* in_scale, const float* in_shift, int in_relu, void* ws,
+                           int64_t ws_bytes, void* stream);
+
 /* ---- pooling: models/resnet.py:110 (MaxPool2d(3,2,1)), :115 (AvgPool2d(7)) ----
  * max-pool reads relu(x*scale+shift) when scale != NULL (stem BN fused); idx = argmax tap (int8). */
 int scat_maxpool3x3s2_fwd(const float* x, const float* scale, const float* shift, int relu, float* y, int8_t* idx,

@@ -32,6 +32,8 @@ struct PwDesc {
     int ntap, KWt, a, tb, c0y, c0x, H, W, OW, OHW;
     FastDiv dOHW, dOW;
     int variant;          // SCAT_TUNE pass-through for kernel-variant experiments
+    const float* src2;    // dual-source (DS) kernels: second tensor and the [3][C] coefficient table
+    const float* coef;
 };
 
 constexpr int PW_KS = 32;     // channels per LDS stage (two 16-channel sub-chunks)
@@ -210,8 +212,12 @@ __global__ __launch_bounds__(NT, (BM * BN >= 128 * 128 ? 2 : 3)) void conv1x1_ke
 // once per element on the way into LDS ([plane][k-octet][pixel][8 bf16], one ds_read_b128 per plane and
 // fragment); the weights are loaded as fp32 straight into registers (lane (row, h): k = 8h..8h+7, 32 bytes) and
 // split there, in the shadow of the previous chunk's MFMAs.
-template <int WM, int BN, bool TF>
+// DS ("dual source"): the operand is a BatchNorm-backward output that was never materialised:
+//   value = ca[c]*src + cb[c]*src2 + cc[c]   (src = masked incoming gradient g, src2 = the layer's raw conv output,
+//   coef = [ca | cb | cc] from scat_bn_bwd_pre).  One register set, activations one stage ahead.
+template <int WM, int BN, bool TF, bool DS = false>
 __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc dc) {
+    static_assert(!(TF && DS), "one input transform at a time");
     constexpr int BM = 32 * WM, WN = 4 / WM, NI = BN / (32 * WN);
     constexpr int NIT = 4 * BN / NT;                  // k-octets staged per thread per 32-channel stage
     static_assert(NIT >= 1, "tile too small");
@@ -253,7 +259,9 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
     }
     // two register sets: the activations of stage s+2 are requested at the top of stage s and written to LDS at the
     // end of stage s+1 (one stage of cover is not enough for an HBM miss at 2 waves per SIMD)
-    float bst[2][NIT][8];
+    float bst[DS ? 1 : 2][NIT][8];
+    float bst2[DS ? NIT : 1][8];
+    const __amdgpu_buffer_rsrc_t rsrc_b2 = make_rsrc(DS ? d.src2 : d.src, DS ? d.nsrc : 0);
     auto load_b = [&](int st, auto set_tag) {         // st >= nstage: every lane reads 0
         constexpr int Q = decltype(set_tag)::value;
         const int tap = st / nsc, c0 = (st - tap * nsc) * PW_KS;
@@ -263,9 +271,13 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
         for (int r = 0; r < NIT; ++r) {
             const int c = c0 + 8 * (g0 + r * (NT / BN));
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
+            for (int m = 0; m < 8; ++m) {
                 bst[Q][r][m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                     rsrc_b, c + m < d.C ? vbase : OOB, (c0 + 8 * r * (NT / BN) + m) * chw4, 0));
+                if constexpr (DS)
+                    bst2[r][m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        rsrc_b2, c + m < d.C ? vbase : OOB, (c0 + 8 * r * (NT / BN) + m) * chw4, 0));
+            }
         }
     };
     // a staging thread's k-octet is the same for its whole wavefront (BN >= 64): the fused transform's constants are
@@ -291,6 +303,12 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
                         t = fmaf(t, d.scale[cc], d.shift[cc]);
                         t = d.relu ? fmaxf(t, 0.f) : t;
                         t = live ? t : 0.f;
+                    }
+                    if constexpr (DS) {
+                        const int c = c0 + 8 * (g0u + r * (NT / BN)) + m;
+                        const int cc = c < d.C ? c : 0;
+                        t = fmaf(d.coef[cc], t, fmaf(d.coef[d.C + cc], bst2[r][m], d.coef[2 * d.C + cc]));
+                        t = (live && c < d.C) ? t : 0.f;
                     }
                     x[u] = t;
                 }
@@ -379,21 +397,16 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    load_b(0, S0{});
-    load_b(1, S1{});
-    load_a(areg[0], 0);
-    store_b(0, Bs(0), S0{});
-    __syncthreads();
-    read_b(bfr[0], Bs(0), 0, 0);
-
-    // stage s: LDS buffer s & 1, register set s & 1 is free again (its data went to LDS one stage ago)
-    auto stage = [&](int s, auto cur_tag) {
-        constexpr int CUR = decltype(cur_tag)::value;
-        const u32x4* bcur = Bs(CUR);
-        u32x4* bnext = Bs(CUR ^ 1);
-        load_b(s + 2, std::integral_constant<int, CUR>{});
-            // the split of stage s+1 (its data landed a stage ago, its LDS buffer has been free since the last
-            // barrier) rides in the shadow of this stage's MFMAs: one slice per MFMA group
+    if constexpr (DS) {
+        load_b(0, S0{});
+        load_a(areg[0], 0);
+        store_b(0, Bs(0), S0{});
+        __syncthreads();
+        read_b(bfr[0], Bs(0), 0, 0);
+        for (int s = 0; s < nstage; ++s) {
+            const u32x4* bcur = Bs(s & 1);
+            u32x4* bnext = Bs((s + 1) & 1);
+            load_b(s + 1, S0{});
             static_for<2 * NI>([&](auto i_tag) {
                 constexpr int I = decltype(i_tag)::value, t = I / NI, b = I % NI;
                 if constexpr (b == 0) load_a(areg[t ^ 1], 2 * s + t + 1);
@@ -401,16 +414,47 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
                 if constexpr (b + 1 < NI) read_b(bfr[fnxt], bcur, t, b + 1);
                 else if constexpr (t == 0) read_b(bfr[fnxt], bcur, 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                store_slice(s + 1, bnext, std::integral_constant<int, CUR ^ 1>{}, i_tag);
                 acc[0][b] = mfma_split(areg[t], bfr[fcur], acc[0][b]);
                 __builtin_amdgcn_sched_barrier(0);
             });
+            store_b(s + 1, bnext, S0{});
+            __syncthreads();
+            read_b(bfr[0], bnext, 0, 0);
+        }
+    } else {
+        load_b(0, S0{});
+        load_b(1, S1{});
+        load_a(areg[0], 0);
+        store_b(0, Bs(0), S0{});
         __syncthreads();
-        read_b(bfr[0], bnext, 0, 0);
-    };
-    for (int s = 0; s < nstage; s += 2) {
-        stage(s, S0{});
-        if (s + 1 < nstage) stage(s + 1, S1{});
+        read_b(bfr[0], Bs(0), 0, 0);
+
+        // stage s: LDS buffer s & 1, register set s & 1 is free again (its data went to LDS one stage ago)
+        auto stage = [&](int s, auto cur_tag) {
+            constexpr int CUR = decltype(cur_tag)::value;
+            const u32x4* bcur = Bs(CUR);
+            u32x4* bnext = Bs(CUR ^ 1);
+            load_b(s + 2, std::integral_constant<int, CUR>{});
+                // the split of stage s+1 (its data landed a stage ago, its LDS buffer has been free since the last
+                // barrier) rides in the shadow of this stage's MFMAs: one slice per MFMA group
+                static_for<2 * NI>([&](auto i_tag) {
+                    constexpr int I = decltype(i_tag)::value, t = I / NI, b = I % NI;
+                    if constexpr (b == 0) load_a(areg[t ^ 1], 2 * s + t + 1);
+                    constexpr int fcur = I & 1, fnxt = fcur ^ 1;
+                    if constexpr (b + 1 < NI) read_b(bfr[fnxt], bcur, t, b + 1);
+                    else if constexpr (t == 0) read_b(bfr[fnxt], bcur, 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    store_slice(s + 1, bnext, std::integral_constant<int, CUR ^ 1>{}, i_tag);
+                    acc[0][b] = mfma_split(areg[t], bfr[fcur], acc[0][b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            __syncthreads();
+            read_b(bfr[0], bnext, 0, 0);
+        };
+        for (int s = 0; s < nstage; s += 2) {
+            stage(s, S0{});
+            if (s + 1 < nstage) stage(s + 1, S1{});
+        }
     }
     store_tile<1, NI, BM, BN, WM, WN>(acc, dc, d.M, d.npix, i0, j0, 0);
 }
@@ -449,12 +493,12 @@ __global__ void w1x1_t_kernel(const float* __restrict__ w, float* __restrict__ w
     }
 }
 
-template <int WM, int BN, bool TF>
+template <int WM, int BN, bool TF, bool DS = false>
 static void launch_pw_split(const PwDesc& d, const OutDesc& dc, hipStream_t st) {
     constexpr int BM = 32 * WM;
     const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, BN);
     constexpr size_t lds_bytes = (size_t)2 * 12 * BN * 16;
-    hipLaunchKernelGGL((conv1x1_split_kernel<WM, BN, TF>), dim3(mt * nt), dim3(NT), lds_bytes, st, d, dc);
+    hipLaunchKernelGGL((conv1x1_split_kernel<WM, BN, TF, DS>), dim3(mt * nt), dim3(NT), lds_bytes, st, d, dc);
 }
 
 template <int BM, int BN, bool V4, bool TF>
@@ -541,6 +585,45 @@ extern "C" int scat_conv2d_fwd_split(const float* x, const float* w, const float
     snprintf(label, sizeof label, "conv%dx%d_s%d", KH, KW, stride);
     taps_split_launch(g, x, w, dc, B, Cin, Cout, in_scale, in_shift, in_relu, ws, label, (hipStream_t)stream);
     SCAT_LAUNCH_CHECK("scat_conv2d_fwd_split");
+    return SCAT_OK;
+}
+
+// Data gradient of a 1x1/stride-1 convolution whose output gradient is a BatchNorm backward that was never
+// materialised: dx[B,Cin,HW] (+)= w^T . (ca*g + cb*z + cc), g = masked incoming gradient [B,Cout,HW] (written by
+// scat_bn_bwd_pre), z = the conv's raw output [B,Cout,HW], coef3 = [ca | cb | cc] per output channel.
+// Split-operand products only; Cout % 16 == 0.  ws: scat_conv1x1_s1_ws(Cin, Cout) bytes.
+extern "C" int scat_conv1x1_s1_bnb(const float* g, const float* z, const float* coef3, const float* w, float* dx, int B,
+                                   int Cin, int HW, int Cout, int accumulate, void* ws, int64_t ws_bytes,
+                                   void* stream) {
+    SCAT_REQUIRE(g && z && coef3 && w && dx, SCAT_E_ARG, "scat_conv1x1_s1_bnb: null pointer");
+    SCAT_REQUIRE(math_mode() == 1, SCAT_E_ARG, "scat_conv1x1_s1_bnb: needs the split-operand product mode");
+    SCAT_REQUIRE(B > 0 && Cin > 0 && HW > 0 && Cout > 0 && Cout % 16 == 0, SCAT_E_SHAPE,
+                 "scat_conv1x1_s1_bnb: bad dimension (Cout must be a multiple of 16)");
+    SCAT_REQUIRE(ws && ws_bytes >= taps_split_ws(Cin, Cout, 1) && ((uintptr_t)ws & 15) == 0, SCAT_E_WORKSPACE,
+                 "scat_conv1x1_s1_bnb: workspace too small / unaligned");
+    SCAT_REQUIRE(fits_i32((int64_t)B * Cout * HW * 4) && fits_i32((int64_t)B * Cin * HW * 4), SCAT_E_SHAPE,
+                 "scat_conv1x1_s1_bnb: tensor exceeds 32-bit byte offsets");
+    hipStream_t st = (hipStream_t)stream;
+    const int C = Cout, M = Cin;
+    PwDesc d{};
+    d.src = g; d.src2 = z; d.coef = coef3;
+    d.C = C; d.M = M; d.HW = HW; d.npix = B * HW; d.dHW = FastDiv::make(HW);
+    d.ntap = 1; d.KWt = 1; d.a = 1; d.tb = 1; d.c0y = 0; d.c0x = 0; d.H = 1; d.W = HW; d.OW = HW; d.OHW = HW;
+    d.dOHW = FastDiv::make(HW); d.dOW = FastDiv::make(HW);
+    d.nsrc = (int64_t)B * C * HW; d.variant = tuning();
+    const int64_t nel = (int64_t)M * ((C + 15) / 16 * 16);
+    const int rblocks = (int)((nel + 255) / 256 < 2048 ? (nel + 255) / 256 : 2048);
+    hipLaunchKernelGGL(w_taps_split_kernel, dim3(rblocks), dim3(256), 0, st, w, (uint16_t*)ws, M, C, 1, 1, 1, 1, 1, 0, 0, 1);
+    d.w = (const float*)ws;
+    d.nw = (nel * 6 + 3) / 4;
+    OutDesc dc{};
+    dc.p = dx; dc.mode = 1; dc.I = M; dc.J = d.npix; dc.C = M; dc.HW = HW; dc.dHW = FastDiv::make(HW);
+    dc.accumulate = accumulate; dc.n = (int64_t)B * M * HW;
+    const int cfg = M > 64 ? 0 : 1;
+    set_kernel_label("conv1x1_split_%sx32_bnb", cfg == 0 ? "128x128" : "64x128");
+    if (cfg == 0) launch_pw_split<4, 128, false, true>(d, dc, st);
+    else launch_pw_split<2, 128, false, true>(d, dc, st);
+    SCAT_LAUNCH_CHECK("scat_conv1x1_s1_bnb");
     return SCAT_OK;
 }
 

@@ -40,7 +40,7 @@ struct WgSplitPlan {
 WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW);
 void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, float* out, int B, int Cin, int H, int W,
                         int Cout, int KK, int stride, const float* in_scale, const float* in_shift, int in_relu,
-                        hipStream_t st);
+                        hipStream_t st, const float* dy2 = nullptr, const float* coef3 = nullptr);
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int splits,
                                      int accumulate);
 

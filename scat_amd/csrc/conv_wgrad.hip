@@ -96,6 +96,38 @@ extern "C" int64_t scat_conv2d_wgrad_ws(int B, int Cin, int H, int W, int Cout, 
     return need;
 }
 
+// Weight gradient of a 1x1/stride-1 convolution from a BatchNorm backward that was never materialised:
+// dy = ca*g + cb*z + cc per output channel (see scat_bn_bwd_pre / scat_conv1x1_s1_bnb).  Split products only.
+extern "C" int scat_conv1x1_wgrad_bnb(const float* g, const float* z, const float* coef3, const float* x, float* dw,
+                                      int B, int Cin, int HW, int Cout, const float* in_scale, const float* in_shift,
+                                      int in_relu, void* ws, int64_t ws_bytes, void* stream) {
+    SCAT_REQUIRE(g && z && coef3 && x && dw, SCAT_E_ARG, "scat_conv1x1_wgrad_bnb: null pointer");
+    SCAT_REQUIRE(math_mode() == 1, SCAT_E_ARG, "scat_conv1x1_wgrad_bnb: needs the split-operand product mode");
+    SCAT_REQUIRE(B > 0 && Cin > 0 && HW > 0 && Cout > 0, SCAT_E_SHAPE, "scat_conv1x1_wgrad_bnb: non-positive dimension");
+    SCAT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), SCAT_E_ARG, "scat_conv1x1_wgrad_bnb: scale/shift pair");
+    SCAT_REQUIRE(fits_i32((int64_t)B * Cout * HW * 4) && fits_i32((int64_t)B * Cin * HW * 4), SCAT_E_SHAPE,
+                 "scat_conv1x1_wgrad_bnb: tensor exceeds 32-bit byte offsets");
+    const WgSplitPlan q = wgrad_split_plan(B, Cin, Cout, 1, HW);
+    const int64_t need = q.splits > 1 ? (int64_t)q.splits * q.M * q.N * sizeof(float) : 0;
+    SCAT_REQUIRE(ws_bytes >= need && (need == 0 || ws), SCAT_E_WORKSPACE,
+                 "scat_conv1x1_wgrad_bnb: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    hipStream_t st = (hipStream_t)stream;
+    wgrad_split_launch(q, g, x, q.splits > 1 ? (float*)ws : dw, B, Cin, 1, HW, Cout, 1, 1, in_scale, in_shift,
+                       in_scale ? in_relu : 0, st, z, coef3);
+    SCAT_LAUNCH_CHECK("scat_conv1x1_wgrad_bnb");
+    if (q.splits > 1) {
+        int64_t n = (int64_t)q.M * q.N;
+        int blocks = (int)((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(64), 0, st, (const float*)ws, dw, n, q.splits, 0);
+        SCAT_LAUNCH_CHECK("scat_conv1x1_wgrad_bnb(reduce)");
+    }
+    return SCAT_OK;
+}
+extern "C" int64_t scat_conv1x1_wgrad_bnb_ws(int B, int Cin, int HW, int Cout) {
+    const WgSplitPlan q = wgrad_split_plan(B, Cin, Cout, 1, HW);
+    return q.splits > 1 ? (int64_t)q.splits * q.M * q.N * sizeof(float) : 0;
+}
+
 extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout,
                                  int KH, int KW, int stride, int pad, const float* in_scale, const float* in_shift,
                                  int in_relu, void* ws, int64_t ws_bytes, void* stream) {

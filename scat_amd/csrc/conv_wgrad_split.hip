@@ -30,6 +30,8 @@ struct WgDesc {
     int spz;              // stages (2 octets each) per split-K slice
     FastDiv dNO, dW, dKK;
     int64_t ndy, nx;
+    const float* dy2;     // DSA kernels: dy = ca[co]*dy + cb[co]*dy2 + cc[co] (BatchNorm backward folded into the load)
+    const float* coef;    // [3][Cout]
 };
 
 // 8 consecutive floats at byte offset off (OOB: zeros).  Two 16-B loads; a vector that would start before or end
@@ -53,7 +55,7 @@ __device__ __forceinline__ void load8(__amdgpu_buffer_rsrc_t rs, int off, uint32
 }
 
 // S2: stride-2 convolution — the 8 pixels of an octet are 8 strided source pixels, fetched as 8 dwords
-template <int KK, int MI, int NI, bool TF, bool S2>
+template <int KK, int MI, int NI, bool TF, bool S2, bool DSA = false>
 __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
     constexpr int OSA = BM + 8, OSB = BN + 8;          // u32x4 per (plane, octet) slab; +128 B keeps the two octets of
@@ -91,10 +93,14 @@ __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc
     const int bshift = (kh - 1) * d.W + (kw - 1);
     float bsc = 1.f, bsh = 0.f;
     if (TF && b_ok) { bsc = d.scale[ci]; bsh = d.shift[ci]; }
+    const __amdgpu_buffer_rsrc_t rsa2 = make_rsrc(DSA ? d.dy2 : d.dy, DSA ? d.ndy : 0);
+    float aca = 1.f, acb = 0.f, acc_ = 0.f;
+    if (DSA && a_ok) { aca = d.coef[arow]; acb = d.coef[d.Cout + arow]; acc_ = d.coef[2 * d.Cout + arow]; }
 
     // two register sets: the loads of stage s+2 are issued at the top of stage s and written to LDS at the end of
     // stage s+1, i.e. ~2 x (MI*NI*6) MFMAs of cover for an HBM miss
     float araw[2][8], braw[2][8];
+    float araw2[DSA ? 8 : 1];                          // DSA runs one stage ahead on a single register set
     uint32_t amask[2] = {0, 0}, bmask[2] = {0, 0};     // validity of the 8 pixels
     auto load_stage = [&](int s, auto set_tag) {
         constexpr int Q = decltype(set_tag)::value;
@@ -109,6 +115,12 @@ __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc
         {
             const int off = (a_ok && cnt > 0) ? (((int)n * d.Cout + arow) * d.OHW + r0) * 4 : OOB;
             load8(rsa, off, a_ok ? live : 0u, d.ndy, araw[Q]);
+            if constexpr (DSA) {
+                float tmp[8];
+                load8(rsa2, off, a_ok ? live : 0u, d.ndy, tmp);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) araw2[e] = tmp[e];
+            }
             amask[Q] = a_ok ? live : 0u;
         }
         // B: x[n][ci][r0 + shift .. +7], per-pixel padding mask
@@ -154,7 +166,11 @@ __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc
         if (a_item) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = ((amask[Q] >> e) & 1u) ? araw[Q][e] : 0.f;
+            for (int e = 0; e < 8; ++e) {
+                float t = araw[Q][e];
+                if constexpr (DSA) t = fmaf(aca, t, fmaf(acb, araw2[e], acc_));
+                v[e] = ((amask[Q] >> e) & 1u) ? t : 0.f;
+            }
             u32x4 hi, mid, lo;
             split3x8(v, hi, mid, lo);
             u32x4* p = As(buf) + so * OSA + srow;
@@ -193,7 +209,8 @@ __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc
     // stage sbeg + t lives in LDS buffer t & 1 and came through register set t & 1
     auto stage = [&](int s, auto cur_tag) {
         constexpr int CUR = decltype(cur_tag)::value;
-        load_stage(s + 2, std::integral_constant<int, CUR>{});      // past the end: every lane reads 0
+        if constexpr (DSA) load_stage(s + 1, S0{});
+        else load_stage(s + 2, std::integral_constant<int, CUR>{});      // past the end: every lane reads 0
         __builtin_amdgcn_sched_barrier(0);
         u32x4 af[MI][3], bf[NI][3];
         const u32x4* pa = As(CUR) + afrag;
@@ -211,12 +228,13 @@ __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc
 #pragma unroll
             for (int b = 0; b < NI; ++b) acc[a][b] = mfma_split(af[a], bf[b], acc[a][b]);
         __builtin_amdgcn_sched_barrier(0);
-        store_stage(CUR ^ 1, std::integral_constant<int, CUR ^ 1>{});   // stage s+1, loaded one stage ago
+        if constexpr (DSA) store_stage(CUR ^ 1, S0{});
+        else store_stage(CUR ^ 1, std::integral_constant<int, CUR ^ 1>{});   // stage s+1, loaded one stage ago
         __syncthreads();
     };
     if (sbeg < send) {
         load_stage(sbeg, S0{});
-        load_stage(sbeg + 1, S1{});
+        if constexpr (!DSA) load_stage(sbeg + 1, S1{});
         store_stage(0, S0{});
     }
     __syncthreads();
@@ -227,13 +245,13 @@ __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc
     store_tile<MI, NI, BM, BN, 2, 2>(acc, dc, d.Cout, d.N, i0, j0, z);
 }
 
-template <int KK, int MI, int NI, bool TF, bool S2>
+template <int KK, int MI, int NI, bool TF, bool S2, bool DSA = false>
 static void launch_wg(const WgDesc& d, const OutDesc& dc, int splits, hipStream_t st) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
     const int mt = cdiv(d.Cout, BM), nt = cdiv(d.N, BN);
     constexpr size_t lds_bytes = (size_t)2 * 6 * (BM + 8 + BN + 8) * 16;
-    hipLaunchKernelGGL((wgrad_split_kernel<KK, MI, NI, TF, S2>), dim3(mt * nt, 1, splits), dim3(NT), lds_bytes, st, d,
-                       dc);
+    hipLaunchKernelGGL((wgrad_split_kernel<KK, MI, NI, TF, S2, DSA>), dim3(mt * nt, 1, splits), dim3(NT), lds_bytes, st,
+                       d, dc);
 }
 
 template <int KK, bool TF, bool S2>
@@ -267,10 +285,19 @@ WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW) {
     return p;
 }
 
+template <bool TF>
+static void launch_wg_dsa(int mi, int ni, const WgDesc& d, const OutDesc& dc, int splits, hipStream_t st) {
+    if (mi == 2 && ni == 2) launch_wg<1, 2, 2, TF, false, true>(d, dc, splits, st);
+    else if (mi == 2) launch_wg<1, 2, 1, TF, false, true>(d, dc, splits, st);
+    else if (ni == 2) launch_wg<1, 1, 2, TF, false, true>(d, dc, splits, st);
+    else launch_wg<1, 1, 1, TF, false, true>(d, dc, splits, st);
+}
+
 void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, float* out, int B, int Cin, int H, int W,
                         int Cout, int KK, int stride, const float* in_scale, const float* in_shift, int in_relu,
-                        hipStream_t st) {
+                        hipStream_t st, const float* dy2, const float* coef3) {
     WgDesc d{};
+    d.dy2 = dy2; d.coef = coef3;
     const int pad = KK == 9 ? 1 : 0, k = KK == 9 ? 3 : 1;
     const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
     d.dy = dy; d.x = x; d.scale = in_scale; d.shift = in_shift; d.relu = in_scale ? in_relu : 0;
@@ -281,9 +308,12 @@ void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, f
     OutDesc dc{};
     dc.p = out; dc.mode = 0; dc.si = p.N; dc.sj = 1; dc.sz = (int64_t)p.M * p.N; dc.I = p.M; dc.J = p.N;
     dc.n = (int64_t)p.M * p.N;
-    set_kernel_label("wgrad%s%s_split_%dx%dx16%s_split%d", KK == 9 ? "3x3" : "1x1", stride == 2 ? "_s2" : "", 64 * p.mi,
-                     64 * p.ni, in_scale ? "_tf" : "", p.splits);
-    if (stride == 2) {
+    set_kernel_label("wgrad%s%s_split_%dx%dx16%s%s_split%d", KK == 9 ? "3x3" : "1x1", stride == 2 ? "_s2" : "", 64 * p.mi,
+                     64 * p.ni, in_scale ? "_tf" : "", dy2 ? "_bnb" : "", p.splits);
+    if (dy2) {      // 1x1 / stride 1 only (checked by the caller)
+        if (in_scale) launch_wg_dsa<true>(p.mi, p.ni, d, dc, p.splits, st);
+        else launch_wg_dsa<false>(p.mi, p.ni, d, dc, p.splits, st);
+    } else if (stride == 2) {
         if (KK == 9) {
             if (in_scale) launch_wg_tile<9, true, true>(p.mi, p.ni, d, dc, p.splits, st);
             else launch_wg_tile<9, false, true>(p.mi, p.ni, d, dc, p.splits, st);

@@ -207,6 +207,71 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, i
     coef[2 * c + 1] = (float)(s2 / count);
 }
 
+// First half of a BatchNorm backward whose second half is folded into the consumers of dx: the masked gradient g
+// replaces dy IN PLACE (it is also the residual branch's gradient), per-channel sums are reduced as above, and the
+// finalize emits the three per-channel constants of   dx = ca*g + cb*x + cc   (from dx = gamma*invstd*(g - mean(g)
+// - xhat*mean(g*xhat)), xhat = (x - mu)*invstd): ca = gamma*invstd, cb = -ca*invstd*mean(g*xhat), cc = -ca*mean(g) - cb*mu.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_g_kernel(float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ yout,
+                                                              const uint8_t* __restrict__ ymask, int relu,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, int B, int C, int HW,
+                                                              int S, FastDiv dHWv, double* __restrict__ part) {
+    const int c = blockIdx.x, s = blockIdx.y;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const int nimg = (B - s + S - 1) / S, hwv = HW / 4;
+    const bool has_m = ymask != nullptr;
+    const bool has_y = yout != nullptr || has_m;
+    double s1 = 0, s2 = 0;
+    for (int idx = threadIdx.x; idx < nimg * hwv; idx += 256) {
+        const int nl = (int)dHWv.div((uint32_t)idx), i = idx - nl * hwv;
+        const int64_t off = ((int64_t)(s + nl * S) * C + c) * HW + i * 4;
+        float xv[4], gv[4], yv[4];
+        float4 t = *(const float4*)(x + off); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+        t = *(const float4*)(dy + off); gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+        if (has_m) {
+            const uint32_t m = ymask[off >> 2];
+            yv[0] = (float)(m & 1u); yv[1] = (float)((m >> 1) & 1u); yv[2] = (float)((m >> 2) & 1u); yv[3] = (float)((m >> 3) & 1u);
+        } else if (has_y) { t = *(const float4*)(yout + off); yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float g = bn_mask(gv[q], xv[q], has_y ? yv[q] : 0.f, has_y, relu, sc, sh);
+            gv[q] = g;
+            s1 += g;
+            s2 += (double)g * ((xv[q] - mu) * is);
+        }
+        *(float4*)(dy + off) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+    }
+    __shared__ double shm[8];
+    block_sum2(s1, s2, shm);
+    if (threadIdx.x == 0) {
+        part[((int64_t)c * S + s) * 2 + 0] = s1;
+        part[((int64_t)c * S + s) * 2 + 1] = s2;
+    }
+}
+
+__global__ void bn_bwd_finalize3_kernel(const double* __restrict__ part, int C, int S, double count,
+                                        const float* __restrict__ gamma, const float* __restrict__ mean,
+                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                        float* __restrict__ dbeta, float* __restrict__ coef3) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int s = 0; s < S; ++s) {
+        s1 += part[((int64_t)c * S + s) * 2];
+        s2 += part[((int64_t)c * S + s) * 2 + 1];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    const float k1 = (float)(s1 / count), k2 = (float)(s2 / count);
+    const float ca = gamma[c] * invstd[c], cb = -ca * invstd[c] * k2;
+    coef3[c] = ca;
+    coef3[C + c] = cb;
+    coef3[2 * C + c] = -ca * k1 - cb * mean[c];
+}
+
 // dx may alias dy, dres may alias dy: every element is read before it is written by the same thread
 template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, const float* __restrict__ x,
@@ -435,6 +500,31 @@ extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, 
                            FastDiv::make(HW), FastDiv::make(C));
     }
     SCAT_LAUNCH_CHECK("scat_bn_bwd");
+    return SCAT_OK;
+}
+
+// g (masked dy) overwrites dy; coef3[3*C] = (ca, cb, cc) with dx = ca*g + cb*x + cc left to the consumers
+// (scat_conv1x1_s1_bnb, scat_conv2d_wgrad_bnb).  HW % 4 == 0 and 16-B aligned tensors only.
+extern "C" int scat_bn_bwd_pre(float* dy_g, const float* x, const float* y_out, const uint8_t* y_mask, int relu,
+                               const float* scale, const float* shift, const float* save_mean,
+                               const float* save_invstd, const float* gamma, float* dgamma, float* dbeta,
+                               float* coef3, int B, int C, int HW, void* ws, int64_t ws_bytes, void* stream) {
+    SCAT_REQUIRE(dy_g && x && scale && shift && save_mean && save_invstd && gamma && dgamma && dbeta && coef3, SCAT_E_ARG,
+                 "scat_bn_bwd_pre: null pointer");
+    SCAT_REQUIRE(B > 0 && C > 0 && HW > 0, SCAT_E_SHAPE, "scat_bn_bwd_pre: non-positive dimension");
+    SCAT_REQUIRE(ws && ws_bytes >= scat_bn_ws(B, C, HW), SCAT_E_WORKSPACE, "scat_bn_bwd_pre: workspace too small");
+    SCAT_REQUIRE(!(y_mask && y_out), SCAT_E_ARG, "scat_bn_bwd_pre: pass the output OR its sign mask");
+    SCAT_REQUIRE((HW & 3) == 0 && (((uintptr_t)dy_g | (uintptr_t)x | (uintptr_t)y_out) & 15) == 0, SCAT_E_SHAPE,
+                 "scat_bn_bwd_pre: needs HW % 4 == 0 and 16-B aligned tensors");
+    SCAT_REQUIRE(fits_i32((int64_t)B * C * HW), SCAT_E_SHAPE, "scat_bn_bwd_pre: tensor exceeds 2^31 elements");
+    const int S = bn_splits(B, C);
+    double* part = (double*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_reduce_g_kernel, dim3(C, S), dim3(256), 0, st, dy_g, x, y_out, y_mask, relu, scale, shift,
+                       save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW / 4), part);
+    hipLaunchKernelGGL(bn_bwd_finalize3_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
+                       (double)B * HW, gamma, save_mean, save_invstd, dgamma, dbeta, coef3);
+    SCAT_LAUNCH_CHECK("scat_bn_bwd_pre");
     return SCAT_OK;
 }
 

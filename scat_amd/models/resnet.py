@@ -66,6 +66,7 @@ class _BNState:
 
 
 _SIDE = {}
+BNB = os.environ.get("SCAT_BNB", "1") != "0"   # fold bn3's backward apply into conv3's gradient kernels
 SIDE_WGRAD = os.environ.get("SCAT_SIDE_WGRAD", "1") != "0"   # bench.py clears it for its serialized, per-kernel-timed step
 
 
@@ -178,6 +179,11 @@ class _BackboneFn(torch.autograd.Function):
             if side is not None:
                 main.wait_stream(side)
 
+        # bn3's backward is split: its reduce masks the incoming gradient in place (that is also the residual
+        # gradient) and leaves  dc3 = ca*g + cb*c3 + cc  to conv3's two gradient kernels, which form it while loading
+        # — dc3 is never written or re-read (SCAT_BNB=0: materialise it, the general path)
+        use_bnb = BNB and ops.get_math_mode() == 1
+
         stage_grads = [dx1, dx2, dx3, dx4]
         # ---- tail: relu(fc1(relu(avgpool(x4))))
         x4 = tape[-1][-2]          # (block output; the last entry is its sign mask)
@@ -201,13 +207,35 @@ class _BackboneFn(torch.autograd.Function):
         for rec in reversed(tape):
             blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out, omask = rec
             # out = relu(bn3(c3) + res): g = dcur * (out>0) is also the residual branch's gradient
-            dc3, dg, db = ops.bn_bwd(dcur, c3, out, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
-                                     gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), dres=dcur, y_mask=omask)
-            put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
             g = dcur
-            put(blk.conv3.weight, wgrad(dc3, c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True))
-            da2 = ops.conv2d_dgrad_w(dc3, blk.conv3.weight, tuple(c2.shape), 1, 0)
-            del dc3
+            ev3 = None
+            w3 = blk.conv3.weight
+            if use_bnb and omask is not None and w3.shape[0] % 16 == 0:
+                coef3, dg, db = ops.bn_bwd_pre(dcur, c3, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
+                                               gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), y_mask=omask)
+                put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
+                out3 = gbuf(w3)
+                if side is None:
+                    put(w3, ops.conv1x1_wgrad_bnb(g, c3, coef3, c2, tuple(w3.shape), s2.scale, s2.shift, True, out=out3))
+                else:
+                    if out3 is None:
+                        out3 = torch.empty_like(w3)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        ops.conv1x1_wgrad_bnb(g, c3, coef3, c2, tuple(w3.shape), s2.scale, s2.shift, True, out=out3,
+                                              ws_slot="side")
+                        ev3 = side.record_event()     # g is overwritten further down this block: wait for this read
+                    g.record_stream(side)
+                    coef3.record_stream(side)
+                    put(w3, out3)
+                da2 = ops.conv1x1_dgrad_bnb(g, c3, coef3, w3, tuple(c2.shape))
+            else:
+                dc3, dg, db = ops.bn_bwd(dcur, c3, out, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
+                                         gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), dres=dcur, y_mask=omask)
+                put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
+                put(w3, wgrad(dc3, c2, w3, 1, 0, s2.scale, s2.shift, True))
+                da2 = ops.conv2d_dgrad_w(dc3, w3, tuple(c2.shape), 1, 0)
+                del dc3
             dc2, dg, db = ops.bn_bwd(da2, c2, None, True, s2.scale, s2.shift, s2.mean, s2.invstd, blk.bn2.weight,
                                      gbuf(blk.bn2.weight), gbuf(blk.bn2.bias), dx=da2)
             put(blk.bn2.weight, dg), put(blk.bn2.bias, db)
@@ -218,6 +246,8 @@ class _BackboneFn(torch.autograd.Function):
                                      gbuf(blk.bn1.weight), gbuf(blk.bn1.bias), dx=da1)
             put(blk.bn1.weight, dg), put(blk.bn1.bias, db)
             put(blk.conv1.weight, wgrad(dc1, xin, blk.conv1.weight, 1, 0))
+            if ev3 is not None:
+                main.wait_event(ev3)      # the side stream's conv3 weight gradient has finished reading g
             if cd is not None:
                 dsw, dsbn = blk.downsample[0].weight, blk.downsample[1]
                 dcd, dg, db = ops.bn_bwd(g, cd, None, False, sd.scale, sd.shift, sd.mean, sd.invstd, dsbn.weight,

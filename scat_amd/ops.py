@@ -285,6 +285,45 @@ def bn_bwd(dy, x, y_out, relu, scale, shift, save_mean, save_invstd, gamma, dgam
     return dx, dgamma, dbeta
 
 
+def bn_bwd_pre(dy, x, relu, scale, shift, save_mean, save_invstd, gamma, dgamma=None, dbeta=None, y_out=None,
+               y_mask=None):
+    """First half of a BatchNorm backward: dy becomes the masked gradient g IN PLACE; returns (coef3[3,C], dgamma,
+    dbeta) with dx = coef3[0]*g + coef3[1]*x + coef3[2], to be applied by conv1x1_dgrad_bnb / conv1x1_wgrad_bnb."""
+    _chk(dy, x, y_out, scale, shift, save_mean, save_invstd, gamma, dgamma, dbeta)
+    B, C, H, W = x.shape
+    dgamma = dgamma if dgamma is not None else torch.empty_like(gamma)
+    dbeta = dbeta if dbeta is not None else torch.empty_like(gamma)
+    coef3 = torch.empty((3, C), dtype=torch.float32, device=x.device)
+    ws = workspace(lib().scat_bn_ws(B, C, H * W), x.device)
+    lib().scat_bn_bwd_pre(_p(dy), _p(x), _p(y_out), _p(y_mask), int(relu), _p(scale), _p(shift), _p(save_mean),
+                          _p(save_invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(coef3), B, C, H * W, _p(ws), ws.numel(),
+                          _stream())
+    return coef3, dgamma, dbeta
+
+
+def conv1x1_dgrad_bnb(g, z, coef3, w, x_shape, out=None, accumulate=False):
+    _chk(g, z, coef3, w, out)
+    B, Cin, H, W = x_shape
+    Cout = w.shape[0]
+    dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=g.device)
+    ws = workspace(lib().scat_conv1x1_s1_ws(Cin, Cout), g.device, "wt")
+    _prof(2.0 * B * H * W * Cout * Cin, lib().scat_conv1x1_s1_bnb, _p(g), _p(z), _p(coef3), _p(w), _p(dx), B, Cin, H * W,
+          Cout, int(accumulate), _p(ws), ws.numel(), _stream())
+    return dx
+
+
+def conv1x1_wgrad_bnb(g, z, coef3, x, w_shape, in_scale=None, in_shift=None, in_relu=False, out=None,
+                      ws_slot="default"):
+    _chk(g, z, coef3, x, in_scale, in_shift, out)
+    B, Cin, H, W = x.shape
+    Cout = w_shape[0]
+    dw = out if out is not None else torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    ws = workspace(lib().scat_conv1x1_wgrad_bnb_ws(B, Cin, H * W, Cout), x.device, ws_slot)
+    _prof(2.0 * B * H * W * Cout * Cin, lib().scat_conv1x1_wgrad_bnb, _p(g), _p(z), _p(coef3), _p(x), _p(dw), B, Cin,
+          H * W, Cout, _p(in_scale), _p(in_shift), int(in_relu), _p(ws), ws.numel(), _stream())
+    return dw
+
+
 # ---------------------------------------------------------------- pooling
 
 def maxpool_fwd(x, scale=None, shift=None, relu=False):

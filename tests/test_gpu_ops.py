@@ -349,6 +349,42 @@ def test_batchnorm_sign_mask(ops):
     assert torch.equal(dres_a, dres_b)
 
 
+@pytest.mark.parametrize("B,cin,cout,H", [(3, 64, 256, 12), (2, 128, 512, 8), (5, 32, 48, 6)])
+def test_batchnorm_backward_folded_into_conv(ops, B, cin, cout, H):
+    """bn_bwd_pre + conv1x1_{dgrad,wgrad}_bnb (the BatchNorm backward's apply formed inside the conv's gradient
+    kernels, dx never materialised) == bn_bwd followed by the plain gradient kernels."""
+    assert ops.get_math_mode() == 1
+    z, res, dy = (g(t(40 + i, n, (B, cout, H, H))) for i, n in enumerate(("z", "res", "dy")))   # z: conv3's raw output
+    a2 = g(t(43, "a2", (B, cin, H, H)))                                                         # conv3's raw input
+    w = g(t(44, "w", (cout, cin, 1, 1), std=(2.0 / cin) ** 0.5))
+    gamma = g(torch.from_numpy(synth.uniform(45, "g", (cout,), 0.5, 1.5)))
+    beta = g(t(46, "b", (cout,), 0.1))
+    sc2 = g(torch.from_numpy(synth.uniform(47, "sc", (cin,), 0.5, 1.5)))
+    sh2 = g(torch.from_numpy(synth.uniform(48, "sh", (cin,), -0.5, 0.5)))
+    rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    mean, invstd, scale, shift = ops.bn_train_stats(z, gamma, beta, rm, rv)
+    y, mask = ops.bn_apply(z, scale, shift, res, True, want_mask=True)
+    # reference composition
+    dres_ref = torch.empty_like(dy)
+    dz, dg_ref, db_ref = ops.bn_bwd(dy, z, y, True, scale, shift, mean, invstd, gamma, dres=dres_ref)
+    dw_ref = ops.conv2d_wgrad(dz, a2, tuple(w.shape), 1, 0, sc2, sh2, True)
+    da_ref = ops.conv2d_dgrad_w(dz, w, tuple(a2.shape), 1, 0)
+    # folded
+    gbuf = dy.clone()
+    coef3, dg, db = ops.bn_bwd_pre(gbuf, z, True, scale, shift, mean, invstd, gamma, y_mask=mask)
+    assert torch.equal(gbuf, dres_ref)                      # g in place == the masked / residual gradient
+    assert rel_err(dg, dg_ref) < 1e-6 and rel_err(db, db_ref) < 1e-6
+    dz_formed = coef3[0].view(1, -1, 1, 1) * gbuf + coef3[1].view(1, -1, 1, 1) * z + coef3[2].view(1, -1, 1, 1)
+    assert rel_err(dz_formed, dz) < 2e-6
+    dw = ops.conv1x1_wgrad_bnb(gbuf, z, coef3, a2, tuple(w.shape), sc2, sh2, True)
+    assert "_bnb" in ops.lib().scat_last_kernel().decode()
+    da = ops.conv1x1_dgrad_bnb(gbuf, z, coef3, w, tuple(a2.shape))
+    assert rel_err(dw, dw_ref) < 2e-5 and rel_err(da, da_ref) < 2e-5
+    base = g(t(49, "acc", tuple(a2.shape)))
+    daa = ops.conv1x1_dgrad_bnb(gbuf, z, coef3, w, tuple(a2.shape), out=base.clone(), accumulate=True)
+    assert rel_err(daa, da_ref + base) < 2e-5
+
+
 def test_pools(ops):
     B, C, H = 3, 16, 112
     x = t(24, "x", (B, C, H, H)).requires_grad_(True)
