@@ -66,6 +66,7 @@ class _BNState:
 
 
 _SIDE = {}
+BNB1 = os.environ.get("SCAT_BNB1", "0") != "0"   # same for bn1 -> conv1: measured slower (its passes hide under the side stream), off
 BNB = os.environ.get("SCAT_BNB", "1") != "0"   # fold bn3's backward apply into conv3's gradient kernels
 SIDE_WGRAD = os.environ.get("SCAT_SIDE_WGRAD", "1") != "0"   # bench.py clears it for its serialized, per-kernel-timed step
 
@@ -179,6 +180,21 @@ class _BackboneFn(torch.autograd.Function):
             if side is not None:
                 main.wait_stream(side)
 
+        def wgrad_bnb(gm, z, coef, xop, w, sc=None, sh=None, relu=False):
+            """conv weight gradient from a folded BatchNorm backward; returns (dw, event after the read of gm)"""
+            out = gbuf(w)
+            if side is None:
+                return ops.conv1x1_wgrad_bnb(gm, z, coef, xop, tuple(w.shape), sc, sh, relu, out=out), None
+            if out is None:
+                out = torch.empty_like(w)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ops.conv1x1_wgrad_bnb(gm, z, coef, xop, tuple(w.shape), sc, sh, relu, out=out, ws_slot="side")
+                ev = side.record_event()
+            gm.record_stream(side)
+            coef.record_stream(side)
+            return out, ev
+
         # bn3's backward is split: its reduce masks the incoming gradient in place (that is also the residual
         # gradient) and leaves  dc3 = ca*g + cb*c3 + cc  to conv3's two gradient kernels, which form it while loading
         # — dc3 is never written or re-read (SCAT_BNB=0: materialise it, the general path)
@@ -214,20 +230,8 @@ class _BackboneFn(torch.autograd.Function):
                 coef3, dg, db = ops.bn_bwd_pre(dcur, c3, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
                                                gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), y_mask=omask)
                 put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
-                out3 = gbuf(w3)
-                if side is None:
-                    put(w3, ops.conv1x1_wgrad_bnb(g, c3, coef3, c2, tuple(w3.shape), s2.scale, s2.shift, True, out=out3))
-                else:
-                    if out3 is None:
-                        out3 = torch.empty_like(w3)
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        ops.conv1x1_wgrad_bnb(g, c3, coef3, c2, tuple(w3.shape), s2.scale, s2.shift, True, out=out3,
-                                              ws_slot="side")
-                        ev3 = side.record_event()     # g is overwritten further down this block: wait for this read
-                    g.record_stream(side)
-                    coef3.record_stream(side)
-                    put(w3, out3)
+                dw3, ev3 = wgrad_bnb(g, c3, coef3, c2, w3, s2.scale, s2.shift, True)   # g is overwritten further down
+                put(w3, dw3)
                 da2 = ops.conv1x1_dgrad_bnb(g, c3, coef3, w3, tuple(c2.shape))
             else:
                 dc3, dg, db = ops.bn_bwd(dcur, c3, out, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
@@ -242,10 +246,19 @@ class _BackboneFn(torch.autograd.Function):
             put(blk.conv2.weight, wgrad(dc2, c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True))
             da1 = ops.conv2d_dgrad_w(dc2, blk.conv2.weight, tuple(c1.shape), blk.stride, 1)
             del dc2, da2
-            dc1, dg, db = ops.bn_bwd(da1, c1, None, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight,
-                                     gbuf(blk.bn1.weight), gbuf(blk.bn1.bias), dx=da1)
-            put(blk.bn1.weight, dg), put(blk.bn1.bias, db)
-            put(blk.conv1.weight, wgrad(dc1, xin, blk.conv1.weight, 1, 0))
+            w1 = blk.conv1.weight
+            fold1 = use_bnb and BNB1 and (c1.shape[2] * c1.shape[3]) % 4 == 0 and w1.shape[0] % 16 == 0
+            if fold1:       # same split for bn1 -> conv1 (mask recomputed from c1: relu(bn1(c1)) was never stored)
+                coef1, dg, db = ops.bn_bwd_pre(da1, c1, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight,
+                                               gbuf(blk.bn1.weight), gbuf(blk.bn1.bias))
+                put(blk.bn1.weight, dg), put(blk.bn1.bias, db)
+                dw1, _ = wgrad_bnb(da1, c1, coef1, xin, w1)
+                put(w1, dw1)
+            else:
+                dc1, dg, db = ops.bn_bwd(da1, c1, None, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight,
+                                         gbuf(blk.bn1.weight), gbuf(blk.bn1.bias), dx=da1)
+                put(blk.bn1.weight, dg), put(blk.bn1.bias, db)
+                put(w1, wgrad(dc1, xin, w1, 1, 0))
             if ev3 is not None:
                 main.wait_event(ev3)      # the side stream's conv3 weight gradient has finished reading g
             if cd is not None:
@@ -258,8 +271,12 @@ class _BackboneFn(torch.autograd.Function):
                 del dcd
             else:
                 dxin = g
-            dcur = ops.conv2d_dgrad_w(dc1, blk.conv1.weight, tuple(xin.shape), 1, 0, out=dxin, accumulate=True)
-            del dc1, da1, g
+            if fold1:
+                dcur = ops.conv1x1_dgrad_bnb(da1, c1, coef1, w1, tuple(xin.shape), out=dxin, accumulate=True)
+            else:
+                dcur = ops.conv2d_dgrad_w(dc1, w1, tuple(xin.shape), 1, 0, out=dxin, accumulate=True)
+                del dc1
+            del da1, g
             remaining -= 1
             if remaining == 0:
                 if sink is not None:
