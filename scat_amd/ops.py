@@ -48,9 +48,9 @@ def _chk(*ts):
 
 
 def workspace(nbytes: int, device, slot: str = "default") -> torch.Tensor:
-    """Caller-owned scratch, grown on demand, one buffer per (device, slot). Stream-ordered reuse
-    is safe because every consumer runs on the current stream."""
-    key = (str(device), slot)
+    """Caller-owned scratch, grown on demand, one buffer per (device, slot, current stream): reuse is stream-ordered,
+    and work issued on another stream (weight gradients, the downsample branch) gets its own buffer."""
+    key = (str(device), slot, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
