@@ -260,3 +260,50 @@ class EncoderTransformer(nn.Module):
 
 
 EncoderTransformerCoarse._draw_mask = EncoderTransformer._draw_mask
+
+
+class EncoderPerformer(nn.Module):
+    """BASELINE config 5: the SCAT token path with FAVOR+ linear attention.  The reference ships only the block
+    (``models.vision_performer.performer_attn_block``) and a patch model (``ViP``); it never wires the block into
+    ``hand_net``.  Wiring chosen here (documented in DESIGN.md): everything of
+    ``EncoderTransformer`` up to the tokens [B,21,784] (ResNet-50, 1x1 reduction of x2, +PE, mask-token scatter),
+    then ``depth`` x ``performer_attn_block(emb_s = 784 // heads, head = heads)`` (dim-preserving, dropout as in the
+    block), a per-token ``Linear(784 -> 3)`` giving the 63 joint offsets, and the same iterative
+    ``Linear(1090 -> 66)`` regressor.  ``opt.vit_heads`` = 16 -> emb_s = 49, m = 24 random features per head."""
+
+    def __init__(self, opt, mean_params, depth=3):
+        super().__init__()
+        from . import vision_performer
+
+        self.mean_params = mean_params.clone().cuda()
+        heads = opt.vit_heads
+        assert 784 % heads == 0, "784 token features must split evenly over the heads (16 -> emb_s 49)"
+        self.full_content = 21
+        self.conv1x1_channel_reduction = snn.Conv2d(512, 21, 1, 1, 0, bias=False)
+        self.blocks = nn.ModuleList([vision_performer.performer_attn_block(784 // heads, heads) for _ in range(depth)])
+        self.to_offsets = snn.Linear(784, 3)
+        self.main_encoder = get_model("resnet50")
+        self.iteration = opt.iteration
+        self.pos_embed = opt.pos_embed
+        self.positionalEncoding = PositionalEncoding(784, max_len=21)
+        self.mask_token = nn.Parameter(torch.randn(1, 1, 784))
+        self.mask_rate = opt.mask_rate
+        self.regressor = snn.Linear(1024 + 66, 66)
+        self._midx_cache = {}
+
+    _draw_mask = EncoderTransformer._draw_mask
+
+    def forward(self, main_input):
+        auto_attach(self)
+        main_feat, x1, x2, x3, x4 = self.main_encoder(main_input)
+        feat_visual = self.conv1x1_channel_reduction(x2)
+        B = feat_visual.size(0)
+        midx = self._draw_mask(feat_visual.device)
+        pe = self.positionalEncoding.pe[0] if self.pos_embed else None
+        tok = _TokensFn.apply(feat_visual.view(B, 21, -1), pe, self.mask_token, midx)
+        for blk in self.blocks:
+            tok = blk(tok)
+        feat_out = self.to_offsets(tok)                                       # [B,21,3]
+        pred_params = _RegressorFn.apply(main_feat, feat_out.reshape(B, -1), self.mean_params.reshape(-1),
+                                         self.regressor.weight, self.regressor.bias, self.iteration)
+        return pred_params, feat_visual

