@@ -43,3 +43,36 @@ def test_metrics_match_numpy():
     ag = gt[:-2] - 2 * gt[1:-1] + gt[2:]
     ap = pred[:-2] - 2 * pred[1:-1] + pred[2:]
     assert np.allclose(M.accel_error(tg, tp).numpy(), np.linalg.norm(ap - ag, axis=2).mean(1))
+
+
+def test_warmup_schedule_and_pretrained_ingest(tmp_path):
+    """train.py:61-63,134 — linear ramp over 15 epochs (stepped with epoch+1), flat afterwards; and a torchvision-style
+    ResNet checkpoint loads into the backbone with only the classifier left over (models/resnet.py:192-195)."""
+    from scat_amd.schedule import WarmupSchedule, load_pretrained_backbone, warmup_lr
+
+    assert warmup_lr(5e-4, 1) == 5e-4 / 15 and warmup_lr(5e-4, 15) == 5e-4 and warmup_lr(5e-4, 40) == 5e-4
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=5e-4)
+    sch = WarmupSchedule(opt, 15)
+    lrs = []
+    for epoch in range(20):
+        sch.step(epoch + 1)
+        lrs.append(opt.param_groups[0]["lr"])
+    assert np.allclose(lrs[:15], 5e-4 * np.arange(1, 16) / 15) and np.allclose(lrs[15:], 5e-4)
+
+    class Bb(torch.nn.Module):          # key layout of a ResNet: conv/bn match, the head is fc1 (not fc)
+        def __init__(self):
+            super().__init__()
+            self.conv1 = torch.nn.Conv2d(3, 4, 3, bias=False)
+            self.bn1 = torch.nn.BatchNorm2d(4)
+            self.fc1 = torch.nn.Linear(4, 2)
+
+    src = {"conv1.weight": torch.ones(4, 3, 3, 3), "bn1.weight": torch.full((4,), 2.0), "bn1.bias": torch.zeros(4),
+           "bn1.running_mean": torch.zeros(4), "bn1.running_var": torch.ones(4), "fc.weight": torch.zeros(1000, 4),
+           "fc.bias": torch.zeros(1000)}
+    f = tmp_path / "resnet.pth"
+    torch.save(src, f)
+    bb = Bb()
+    missing, unexpected = load_pretrained_backbone(bb, str(f))
+    assert set(unexpected) == {"fc.weight", "fc.bias"} and {"fc1.weight", "fc1.bias"} <= set(missing)
+    assert torch.equal(bb.conv1.weight.data, src["conv1.weight"]) and torch.equal(bb.bn1.weight.data, src["bn1.weight"])
