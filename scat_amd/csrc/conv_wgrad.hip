@@ -71,11 +71,12 @@ static void wgrad_gemm(const WgradPlan& p, const GatherDesc& da, const GatherDes
     wgrad_gemm_tf<KH, KW, AV4, BV4, false>(p, da, db, dc, st);
 }
 
-// measured at batch 96: the split kernel wins except where the output is tiny and the contraction huge
-// (layer1's 64x64 / 64x256 1x1 convs: staging-bound 64-row tiles), which stay on the fp32 engine
+// measured at batch 96: the split kernel wins or ties everywhere it applies (tiny outputs with huge contractions —
+// ResNet layer1's 64x64 1x1, HRNet's 32-channel 3x3 — are staging-bound on both engines; SCAT_WG_MINMN sets a floor
+// on Cout*Cin*k*k below which the fp32 engine is used instead)
 static bool wgrad_split_ok(int KH, int stride, int pad, int Cout, int Cin) {
     // (1x1/stride 2: the strided 8-dword gather makes the split kernel staging-bound, 315-380 us vs 240-250 us)
-    static const int64_t minmn = [] { const char* e = getenv("SCAT_WG_MINMN"); return e ? atoll(e) : 64ll * 256; }();
+    static const int64_t minmn = [] { const char* e = getenv("SCAT_WG_MINMN"); return e ? atoll(e) : 0ll; }();
     return ((KH == 1 && pad == 0 && stride == 1) || (KH == 3 && pad == 1)) && (int64_t)Cout * Cin * KH * KH > minmn;
 }
 

@@ -2,18 +2,70 @@
 ``HRNet(c, nof_joints, bn_momentum)``, stem (two stride-2 3x3 convs), ``layer1`` (4 Bottlenecks),
 ``transition1..3``, ``stage2..4`` of ``StageModule`` (4 BasicBlocks per branch + fuse layers with
 1x1+BN+nearest-upsample / strided 3x3 chains), ``final_layer`` 1x1 with bias — identical
-``state_dict`` keys.  Every conv / BN / ReLU / upsample / add runs on libscat_hip kernels (per-layer
-autograd nodes; the fused single-node executor used for ResNet-50 is the planned next step for this
-many-small-conv graph).
+``state_dict`` keys.  Every conv / BN / ReLU / upsample / add runs on libscat_hip kernels; the BasicBlocks of the
+stage branches (208 of the 293 convs) execute as one fused autograd node each (``_BasicBlockFn``), the rest as
+per-layer nodes.
 
 Quirk kept: ``BasicBlock.conv2`` is declared ``inplanes -> planes`` (hrnet.py:56), harmless because
 inplanes == planes wherever it is used.
 """
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 
 from .. import nn as snn
+from .. import ops
+from . import resnet as _rn
+
+
+class _BasicBlockFn(torch.autograd.Function):
+    """A stride-1 BasicBlock without projection (every block of the StageModule branches: 208 of HRNet-W32's 293
+    convs) as ONE autograd node, the same way the ResNet Bottleneck is executed: bn1+ReLU is never materialised (folded
+    into conv2's operand load forward and into the weight gradient backward, the mask recomputed from the raw conv
+    output), bn2 + residual add + ReLU is one pass that also leaves a 1-bit sign mask for the backward, the BatchNorm
+    backward runs in place, and conv1's data gradient accumulates straight into the residual gradient."""
+
+    @staticmethod
+    def forward(ctx, x, blk, w1, g1, b1, w2, g2, b2):
+        training = blk.training
+        x = x if x.is_contiguous() else x.contiguous()
+        c1 = ops.conv2d_fwd(x, w1, 1, 1)
+        s1 = _rn._BNState(c1, blk.bn1, training)
+        c2 = ops.conv2d_fwd(c1, w2, 1, 1, s1.scale, s1.shift, True)
+        s2 = _rn._BNState(c2, blk.bn2, training)
+        if _rn._NBT:
+            torch._foreach_add_(_rn._NBT, 1)
+            _rn._NBT.clear()
+        need = training and any(ctx.needs_input_grad)
+        if need:
+            out, mask = ops.bn_apply(c2, s2.scale, s2.shift, x, True, want_mask=True)
+            ctx.blk, ctx.s1, ctx.s2, ctx.has_mask = blk, s1, s2, mask is not None
+            ctx.save_for_backward(x, c1, c2, mask if mask is not None else out)
+        else:
+            out = ops.bn_apply(c2, s2.scale, s2.shift, x, True)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, c1, c2, m = ctx.saved_tensors
+        blk, s1, s2 = ctx.blk, ctx.s1, ctx.s2
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        g = torch.empty_like(dout)          # masked gradient = the residual branch's gradient (dout itself is autograd's)
+        dc2, dg2, db2 = ops.bn_bwd(dout, c2, None if ctx.has_mask else m, True, s2.scale, s2.shift, s2.mean, s2.invstd,
+                                   blk.bn2.weight, dres=g, y_mask=m if ctx.has_mask else None)
+        dw2 = ops.conv2d_wgrad(dc2, c1, tuple(blk.conv2.weight.shape), 1, 1, s1.scale, s1.shift, True)
+        da1 = ops.conv2d_dgrad_w(dc2, blk.conv2.weight, tuple(c1.shape), 1, 1)
+        del dc2
+        dc1, dg1, db1 = ops.bn_bwd(da1, c1, None, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight, dx=da1)
+        dw1 = ops.conv2d_wgrad(dc1, x, tuple(blk.conv1.weight.shape), 1, 1)
+        dx = ops.conv2d_dgrad_w(dc1, blk.conv1.weight, tuple(x.shape), 1, 1, out=g, accumulate=True)
+        return dx, None, dw1, dg1, db1, dw2, dg2, db2
+
+
+import os
+
+FUSED_BASIC = os.environ.get("SCAT_HRNET_FUSED", "1") != "0"   # 0: the per-layer autograd path, for A/B runs
 
 
 class Bottleneck(nn.Module):
@@ -53,6 +105,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if FUSED_BASIC and self.downsample is None and self.stride == 1 and x.is_cuda:
+            return _BasicBlockFn.apply(x, self, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
+                                       self.bn2.weight, self.bn2.bias)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
         residual = x if self.downsample is None else self.downsample(x)

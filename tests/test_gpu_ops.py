@@ -227,8 +227,7 @@ def test_wgrad_stride1(ops, math_mode, math, B, cin, cout, H, W, k):
         a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if tf else x
         ref = torch.nn.grad.conv2d_weight(a.double(), w_shape, dy.double(), padding=k // 2)
         got = ops.conv2d_wgrad(g(dy), g(x), w_shape, 1, k // 2, *((g(sc), g(sh), True) if tf else ()))
-        # (outputs of <= 64x256 weights stay on the fp32 engine in either mode)
-        assert ("_split_" in ops.lib().scat_last_kernel().decode()) == (bool(math) and cout * cin * k * k > 64 * 256)
+        assert ("_split_" in ops.lib().scat_last_kernel().decode()) == bool(math)
         assert rel_err(got, ref) < 2e-5, tf
 
 
