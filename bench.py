@@ -141,6 +141,7 @@ def dominant_kernel_roofline(ts, x, lab):
             "frac": round(tf / peak, 4), "traffic": traffic, "kernel": name, "launches_per_step": n,
             "peak_basis": ("2500 TF dense bf16 MFMA / 6 bf16 terms per fp32 product" if split
                            else "157.3 TF fp32 MFMA"),
+            "frac_of_fp32_mfma_peak": round(tf / PEAK_F32_MFMA_TF, 4),
             "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3)}
     return roof, table
 
