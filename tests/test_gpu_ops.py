@@ -212,7 +212,8 @@ def test_split_products_are_as_accurate_as_fp32(ops, math_mode):
 @pytest.mark.parametrize("math", [0, 1])
 @pytest.mark.parametrize("B,cin,cout,H,W,k", [(2, 20, 136, 9, 13, 3), (3, 36, 64, 7, 7, 3), (2, 64, 132, 30, 4, 3),
                                                (5, 128, 128, 14, 14, 3), (2, 144, 136, 9, 13, 1), (3, 160, 112, 7, 7, 1),
-                                               (1, 96, 208, 5, 64, 1), (4, 3, 5, 6, 5, 3)])
+                                               (1, 96, 208, 5, 64, 1), (4, 3, 5, 6, 5, 3), (2, 40, 48, 9, 13, 1),
+                                               (6, 72, 32, 28, 28, 3), (1, 32, 64, 5, 64, 1), (3, 64, 64, 56, 56, 1)])
 def test_wgrad_stride1(ops, math_mode, math, B, cin, cout, H, W, k):
     """weight gradient of 1x1/pad 0 and 3x3/pad 1: planes that are not a multiple of 8 pixels (ragged octets), rows
     shorter than an octet (taps wrap inside a vector, first/last vectors poke outside the tensor), ragged
