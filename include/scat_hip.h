@@ -151,6 +151,10 @@ int scat_avgpool_fwd(const float* x, float* y, int B, int C, int HW, int relu, v
 int scat_avgpool_bwd(const float* dy, const float* y, int relu, float* dx, int B, int C, int HW, int accumulate,
                      void* stream);
 
+/* y[B,C,ceil(H/2),ceil(W/2)] = x[:,:,::2,::2] — the pixels the 1x1/stride-2 shortcut convolution reads
+ * (models/resnet.py:127-132), packed once so that its forward and weight gradient run at stride 1. */
+int scat_subsample2(const float* x, float* y, int B, int C, int H, int W, void* stream);
+
 /* ---- LayerNorm over the last dim (eps 1e-5): models/vision_transformer.py:20-26 ---- */
 int scat_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                        int rows, int dim, float eps, void* stream);

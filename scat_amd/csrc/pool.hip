@@ -136,6 +136,28 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     }
 }
 
+// y[b,c,oy,ox] = x[b,c,2*oy,2*ox]: the pixels a 1x1/stride-2 convolution reads, packed so that its forward and weight
+// gradient run as stride-1 pointwise convolutions (resnet.py:127-132 shortcut).  P = outputs per thread.
+template <int P>
+__global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         int64_t total, int H, int W, int OH, int OW) {
+    const int OWP = OW / P;
+    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+        const int64_t row = e / OWP;
+        const int q = (int)(e - row * OWP);
+        const int64_t bc = row / OH;
+        const int oy = (int)(row - bc * OH);
+        const float* src = x + (bc * H + 2 * oy) * W + 2 * P * q;
+        float* dst = y + row * OW + P * q;
+        if constexpr (P == 2) {
+            const float4 v = *reinterpret_cast<const float4*>(src);
+            *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.z);
+        } else {
+            dst[0] = src[0];
+        }
+    }
+}
+
 static inline int grid_for(int64_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
 
 }  // namespace scat
@@ -189,5 +211,22 @@ extern "C" int scat_avgpool_bwd(const float* dy, const float* y, int relu, float
     hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, y, relu, dx,
                        total, HW, accumulate);
     SCAT_LAUNCH_CHECK("scat_avgpool_bwd");
+    return SCAT_OK;
+}
+
+extern "C" int scat_subsample2(const float* x, float* y, int B, int C, int H, int W, void* stream) {
+    SCAT_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, SCAT_E_ARG, "scat_subsample2: bad argument");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const int64_t rows = (int64_t)B * C * OH;
+    if (W % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0) {
+        const int64_t total = rows * (OW / 2);
+        hipLaunchKernelGGL(subsample2_kernel<2>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, total, H,
+                           W, OH, OW);
+    } else {
+        const int64_t total = rows * OW;
+        hipLaunchKernelGGL(subsample2_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, total, H,
+                           W, OH, OW);
+    }
+    SCAT_LAUNCH_CHECK("scat_subsample2");
     return SCAT_OK;
 }

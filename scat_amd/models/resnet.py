@@ -53,7 +53,7 @@ _NBT = []   # num_batches_tracked buffers touched by the running forward: bumped
 
 class _BNState:
     """Per-BN tensors produced in forward and consumed in backward."""
-    __slots__ = ("mean", "invstd", "scale", "shift")
+    __slots__ = ("mean", "invstd", "scale", "shift", "xs")
 
     def __init__(self, x, bn, training):
         if training:
@@ -68,6 +68,7 @@ class _BNState:
 _SIDE = {}
 BNB1 = os.environ.get("SCAT_BNB1", "0") != "0"   # same for bn1 -> conv1: measured slower (its passes hide under the side stream), off
 BNB = os.environ.get("SCAT_BNB", "1") != "0"   # fold bn3's backward apply into conv3's gradient kernels
+SUBSAMPLE = os.environ.get("SCAT_SUBSAMPLE", "1") != "0"   # pack the input of the 1x1/stride-2 shortcuts (stride-1 kernels)
 SIDE_WGRAD = os.environ.get("SCAT_SIDE_WGRAD", "1") != "0"   # bench.py clears it for its serialized, per-kernel-timed step
 
 
@@ -105,8 +106,15 @@ class _BackboneFn(torch.autograd.Function):
                 c3 = ops.conv2d_fwd(c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True)
                 s3 = _BNState(c3, blk.bn3, training)
                 if blk.downsample is not None:
-                    cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0)
+                    # stride-2 shortcut: pack the pixels it reads once, then it (and its weight gradient) is a
+                    # stride-1 pointwise convolution
+                    xs = ops.subsample2(xin) if blk.stride == 2 and SUBSAMPLE else None
+                    if xs is not None:
+                        cd = ops.conv2d_fwd(xs, blk.downsample[0].weight, 1, 0)
+                    else:
+                        cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0)
                     sd = _BNState(cd, blk.downsample[1], training)
+                    sd.xs = xs if training else None
                     res = ops.bn_apply(cd, sd.scale, sd.shift, None, False)
                 else:
                     cd = sd = None
@@ -266,7 +274,10 @@ class _BackboneFn(torch.autograd.Function):
                 dcd, dg, db = ops.bn_bwd(g, cd, None, False, sd.scale, sd.shift, sd.mean, sd.invstd, dsbn.weight,
                                          gbuf(dsbn.weight), gbuf(dsbn.bias), dx=g)
                 put(dsbn.weight, dg), put(dsbn.bias, db)
-                put(dsw, wgrad(dcd, xin, dsw, blk.stride, 0))
+                if sd.xs is not None:
+                    put(dsw, wgrad(dcd, sd.xs, dsw, 1, 0))
+                else:
+                    put(dsw, wgrad(dcd, xin, dsw, blk.stride, 0))
                 dxin = ops.conv2d_dgrad_w(dcd, dsw, tuple(xin.shape), blk.stride, 0)
                 del dcd
             else:

@@ -344,6 +344,15 @@ def maxpool_bwd(dy, idx, x_shape):
     return dx
 
 
+def subsample2(x):
+    """x[:, :, ::2, ::2] packed (the input of a 1x1/stride-2 convolution as a stride-1 one sees it)"""
+    _chk(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    lib().scat_subsample2(_p(x), _p(y), B, C, H, W, _stream())
+    return y
+
+
 def avgpool_fwd(x, relu=True):
     _chk(x)
     B, C, H, W = x.shape

@@ -387,7 +387,9 @@ def test_split_products_train_like_fp32_mfma():
     (l0, p0), (l1, p1) = traj[0], traj[1]
     assert rel_err(p1, p0) < 2e-5                      # forward: both are fp32-accurate
     assert abs(l1[0] - l0[0]) / abs(l0[0]) < 2e-5
-    assert abs(l1[1] - l0[1]) / abs(l0[1]) < 1e-4      # one Adam step later: still together
+    # one Adam step later: as close as two fp32-MFMA summation orders of the same network are (mode 0 with and
+    # without the packed stride-2 shortcut input, i.e. a different fp32 kernel for 3 convolutions: 6.5e-4 apart here)
+    assert abs(l1[1] - l0[1]) / abs(l0[1]) < 2e-3
     for a, b in zip(l0[2:], l1[2:]):                   # then the run is chaotic (the loss swings 7x in 6 steps at this
         assert abs(a - b) / abs(a) < 3e-2, (l0, l1)    # init): measured 0.3 % .. 1.2 % apart, as two fp32 orders are
 

@@ -271,6 +271,13 @@ def test_wgrad_stride2_split(ops, B, cin, cout, H, W, k):
         assert rel_err(got, ref) < 2e-5, tf
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (3, 5, 7, 9), (1, 2, 14, 14), (2, 4, 5, 12), (1, 1, 1, 1)])
+def test_subsample2(ops, shape):
+    """x[:, :, ::2, ::2] packed: even/odd planes, vector and scalar paths; bit-exact (a copy)."""
+    x = t(98, "x", shape)
+    assert torch.equal(ops.subsample2(g(x)).cpu(), x[:, :, ::2, ::2].contiguous())
+
+
 def test_conv_bias_and_edge_batches(ops):
     for B in (1, 5):
         x = t(10, "x", (B, 20, 9, 9))

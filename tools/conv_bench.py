@@ -20,6 +20,8 @@ SHAPES = [  # Cin, Cout, k, s, p, H
     (256, 1024, 1, 1, 0, 14), (512, 1024, 1, 2, 0, 28), (1024, 256, 1, 1, 0, 14), (256, 256, 3, 1, 1, 14),
     (1024, 512, 1, 1, 0, 14), (512, 512, 3, 2, 1, 14), (512, 2048, 1, 1, 0, 7), (1024, 2048, 1, 2, 0, 14),
     (2048, 512, 1, 1, 0, 7), (512, 512, 3, 1, 1, 7),
+    # 23-25: the stride-2 shortcut convolutions seen as stride-1 on a pre-subsampled input
+    (256, 512, 1, 1, 0, 28), (512, 1024, 1, 1, 0, 14), (1024, 2048, 1, 1, 0, 7),
 ]
 
 
