@@ -47,7 +47,7 @@ int scat_conv2d_dgrad(const float* dy, const float* wt, float* dx, int B, int Ci
  * zeros.  Takes the ORIGINAL weights w[Cout,Cin,KH,KW]; ws: scat_conv2d_dgrad_s2_ws() bytes. */
 int64_t scat_conv2d_dgrad_s2_ws(int Cin, int Cout, int KH, int KW);
 int scat_conv2d_dgrad_s2(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W, int Cout, int KH,
-                         int KW, int pad, int accumulate, void* ws, int64_t ws_bytes, void* stream);
+                         int KW, int pad, int accumulate, void* ws, int64_t ws_bytes, int w_ready, void* stream);
 /* How the contraction kernels that support it form fp32 products (scat_conv3x3_s1 today):
  *   0  v_mfma_f32_32x32x2_f32 — the fp32 matrix instruction (64 FLOP/clk/SIMD);
  *   1  each fp32 operand split into three bf16 terms (round-to-nearest), six v_mfma_f32_32x32x16_bf16 products
@@ -63,14 +63,14 @@ int scat_set_math_mode(int mode);
 int64_t scat_conv3x3_s1_ws(int Cout, int Cin);
 int scat_conv3x3_s1(const float* src, const float* w, float* dst, int B, int Cin, int H, int W, int Cout,
                     int transposed, const float* in_scale, const float* in_shift, int in_relu, int accumulate,
-                    void* ws, int64_t ws_bytes, void* stream);
+                    void* ws, int64_t ws_bytes, int w_ready, void* stream);
 /* Forward conv (1x1 / 3x3, stride 1 or 2) on the split-operand taps kernel: contraction ordered (tap, channel),
  * weights re-laid and split per call into ws (scat_conv2d_fwd_split_ws bytes).  Needs scat_get_math_mode() == 1 and
  * Cin % 16 == 0.  The library's path for the stride-2 convolutions (models/resnet.py:68,131-135). */
 int64_t scat_conv2d_fwd_split_ws(int Cout, int Cin, int KH, int KW);
 int scat_conv2d_fwd_split(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
                           int Cout, int KH, int KW, int stride, int pad, const float* in_scale, const float* in_shift,
-                          int in_relu, void* ws, int64_t ws_bytes, void* stream);
+                          int in_relu, void* ws, int64_t ws_bytes, int w_ready, void* stream);
 /* Pointwise (1x1, stride 1, pad 0) conv: dst[B,M,HW] (+)= A[M,C] . relu(src[B,C,HW]*scale+shift) (+ bias[M]).
  * Weights go straight from L2 to the MFMA operand registers, activations through LDS 32 channels per barrier.
  * transposed = 0 (forward): w = [M,C] = the conv weight [Cout,Cin];  transposed = 1 (data gradient): w = [C,M] is
@@ -80,7 +80,28 @@ int scat_conv2d_fwd_split(const float* x, const float* w, const float* bias, flo
 int64_t scat_conv1x1_s1_ws(int M, int C);
 int scat_conv1x1_s1(const float* src, const float* w, float* dst, int B, int C, int HW, int M, int transposed,
                     const float* bias, const float* in_scale, const float* in_shift, int in_relu, int accumulate,
-                    void* ws, int64_t ws_bytes, void* stream);
+                    void* ws, int64_t ws_bytes, int w_ready, void* stream);
+/* ---- prepared weights (split-operand products) ----
+ * The five entry points above that take `w_ready` re-lay their weights into ws (three bf16 planes in MFMA operand
+ * order) before their main kernel: one small launch per convolution and direction, 114 per ResNet-50 train step
+ * (53 nn.Conv2d of models/resnet.py x forward + data gradient).  With w_ready = 1 the caller promises that ws
+ * already holds that re-layout and the launch is skipped.  scat_wprep_jobs() writes the description of one
+ * (weight, kind) re-layout — 1 job, or up to 4 for the parity classes of the stride-2 data gradient — into HOST
+ * memory at jobs_out (scat_wprep_job_bytes() each), numbered from block blk0, and returns the first free block (< 0:
+ * SCAT_E_*); the caller concatenates the jobs of a whole network, uploads the table once and runs it with ONE
+ * launch after each weight update (scat_wprep_run).  ws must be the buffer later passed to the entry point
+ * (16-B aligned, the entry's *_ws() bytes); Cout/Cin/KH/KW/pad are those of w[Cout,Cin,KH,KW].  The library
+ * keeps no state: the table and the workspaces belong to the caller. */
+#define SCAT_WPREP_CONV1X1_FWD 0   /* scat_conv1x1_s1, transposed = 0 */
+#define SCAT_WPREP_CONV1X1_DGRAD 1 /* scat_conv1x1_s1, transposed = 1; scat_conv1x1_s1_bnb */
+#define SCAT_WPREP_CONV3X3_FWD 2   /* scat_conv3x3_s1, transposed = 0 */
+#define SCAT_WPREP_CONV3X3_DGRAD 3 /* scat_conv3x3_s1, transposed = 1 */
+#define SCAT_WPREP_FWD_SPLIT 4     /* scat_conv2d_fwd_split */
+#define SCAT_WPREP_DGRAD_S2 5      /* scat_conv2d_dgrad_s2 */
+int64_t scat_wprep_job_bytes(void);
+int64_t scat_wprep_jobs(int kind, const float* w, void* ws, int64_t ws_bytes, int Cout, int Cin, int KH, int KW, int pad,
+                        int64_t blk0, void* jobs_out, int max_jobs, int* njobs_out);
+int scat_wprep_run(const void* jobs_dev, int njobs, int64_t nblocks, void* stream);
 /* wt[Cin][Cout*KH*KW] = w[Cout][Cin][KH][KW] re-laid for the data-gradient contraction. */
 int scat_conv2d_wt(const float* w, float* wt, int Cout, int Cin, int KH, int KW, void* stream);
 /* dw[Cout,Cin,KH,KW] = sum over pixels dy * relu(x*scale+shift).  Deterministic two-stage
@@ -134,7 +155,7 @@ int scat_bn_bwd_pre(float* dy_g, const float* x, const float* y_out, const uint8
 /* dx[B,Cin,HW] (+)= w^T . (ca*g + cb*z + cc): data gradient of a 1x1 conv whose output gradient is the BatchNorm
  * backward above (g, coef3 from scat_bn_bwd_pre; z = the conv's raw output).  ws: scat_conv1x1_s1_ws(Cin, Cout). */
 int scat_conv1x1_s1_bnb(const float* g, const float* z, const float* coef3, const float* w, float* dx, int B, int Cin,
-                        int HW, int Cout, int accumulate, void* ws, int64_t ws_bytes, void* stream);
+                        int HW, int Cout, int accumulate, void* ws, int64_t ws_bytes, int w_ready, void* stream);
 /* dw[Cout,Cin] = sum over pixels (ca*g + cb*z + cc)[co] * relu(x*scale+shift)[ci]: the same conv's weight gradient. */
 int64_t scat_conv1x1_wgrad_bnb_ws(int B, int Cin, int HW, int Cout);
 int scat_conv1x1_wgrad_bnb(const float* g, const float* z, const float* coef3, const float* x, float* dw, int B, int Cin,

@@ -1,6 +1,8 @@
 // Convolution forward / data-gradient on the fp32 MFMA engine (weight-gradient: conv_wgrad.hip).
 // Replaces nn.Conv2d (+ its autograd) as called at models/resnet.py:65-72,105,129 and
 // models/hand_net.py:329 of the reference.
+#include <string.h>
+
 #include "conv_common.h"
 
 namespace scat {
@@ -183,13 +185,40 @@ extern "C" int scat_conv2d_dgrad(const float* dy, const float* wt, float* dx, in
 
 extern "C" int64_t scat_conv2d_dgrad_s2_ws(int Cin, int Cout, int KH, int KW) {
     const int64_t f32 = (int64_t)Cin * Cout * KH * KW * sizeof(float);
-    const int64_t split = taps_split_ws(Cin, Cout, KH == 1 ? 1 : 4);   // largest parity class: 2x2 taps
+    const int64_t split = taps_split_ws(Cin, Cout, KH * KW);           // every parity class has its own slice
     return f32 > split ? f32 : split;
 }
 
+// the parity classes of the stride-2 data gradient, in launch order: taps (kh0 + 2*th, kw0 + 2*tw) of w
+struct S2Class { int py, px, kh0, kw0, KHc, KWc; int64_t ws_off; };
+static int dgrad_s2_classes(int Cin, int Cout, int KH, int KW, int pad, S2Class* out) {
+    int n = 0;
+    int64_t off = 0;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            const int kh0 = (py + pad) & 1, kw0 = (px + pad) & 1;
+            const int KHc = (KH - kh0 + 1) / 2, KWc = (KW - kw0 + 1) / 2;   // taps of matching parity
+            if (KHc <= 0 || KWc <= 0) continue;                             // 1x1: only class (0,0) has a tap
+            out[n++] = S2Class{py, px, kh0, kw0, KHc, KWc, off};
+            off += taps_split_ws(Cin, Cout, KHc * KWc);
+        }
+    return n;
+}
+
+namespace scat {
+int dgrad_s2_wprep_jobs(const float* w, void* ws, int Cin, int Cout, int KH, int KW, int pad, WPrepJob* out) {
+    S2Class cls[4];
+    const int n = dgrad_s2_classes(Cin, Cout, KH, KW, pad, cls);
+    for (int k = 0; k < n; ++k)
+        out[k] = wprep_job(w, (char*)ws + cls[k].ws_off, Cin, Cout, 1, KH, KW, cls[k].KHc * cls[k].KWc, cls[k].KWc,
+                           cls[k].kh0, cls[k].kw0, 2);
+    return n;
+}
+}  // namespace scat
+
 extern "C" int scat_conv2d_dgrad_s2(const float* dy, const float* w, float* dx, int B, int Cin, int H, int W,
                                     int Cout, int KH, int KW, int pad, int accumulate, void* ws, int64_t ws_bytes,
-                                    void* stream) {
+                                    int w_ready, void* stream) {
     int OH, OW;
     if (int e = check_geom("scat_conv2d_dgrad_s2", B, Cin, H, W, Cout, KH, KW, 2, pad, &OH, &OW)) return e;
     SCAT_REQUIRE(dy && w && dx, SCAT_E_ARG, "scat_conv2d_dgrad_s2: null pointer");
@@ -206,14 +235,18 @@ extern "C" int scat_conv2d_dgrad_s2(const float* dy, const float* w, float* dx, 
         }
     }
     float* wtc = (float*)ws;
-    for (int py = 0; py < 2; ++py) {
-        for (int px = 0; px < 2; ++px) {
-            const int kh0 = (py + pad) & 1, kw0 = (px + pad) & 1;
-            const int KHc = (KH - kh0 + 1) / 2, KWc = (KW - kw0 + 1) / 2;   // taps of matching parity
+    const bool split_ok = math_mode() == 1 && Cout % 16 == 0 && ((uintptr_t)ws & 15) == 0;
+    SCAT_REQUIRE(!w_ready || split_ok, SCAT_E_ARG, "scat_conv2d_dgrad_s2: prepared weights exist for split products only");
+    S2Class cls[4];
+    const int ncls = dgrad_s2_classes(Cin, Cout, KH, KW, pad, cls);
+    for (int k = 0; k < ncls; ++k) {
+        {
+            const int py = cls[k].py, px = cls[k].px, kh0 = cls[k].kh0, kw0 = cls[k].kw0;
+            const int KHc = cls[k].KHc, KWc = cls[k].KWc;
             const int QH = (H - py + 1) / 2, QW = (W - px + 1) / 2;         // input pixels in this class
-            if (KHc <= 0 || KWc <= 0 || QH <= 0 || QW <= 0) continue;       // 1x1: only class (0,0) has a tap
+            if (QH <= 0 || QW <= 0) continue;
             const int KKc = KHc * KWc, K = Cout * KKc, N = B * QH * QW;
-            if (math_mode() == 1 && Cout % 16 == 0 && ((uintptr_t)ws & 15) == 0) {
+            if (split_ok) {
                 // split-operand taps kernel: class pixel (qy, qx), tap (kky, kkx) reads dy(qy + (py+pad)/2 - kky, ...)
                 TapsGeom g{};
                 g.H = OH; g.W = OW; g.OH = QH; g.OW = QW; g.a = 1; g.tb = -1;
@@ -225,7 +258,8 @@ extern "C" int scat_conv2d_dgrad_s2(const float* dy, const float* w, float* dx, 
                 dc.dQW = FastDiv::make(QW); dc.accumulate = accumulate; dc.n = (int64_t)B * Cin * H * W;
                 char label[40];
                 snprintf(label, sizeof label, "dgrad_s2_class%dx%d", KHc, KWc);
-                taps_split_launch(g, dy, w, dc, B, Cout, Cin, nullptr, nullptr, 0, ws, label, st);
+                taps_split_launch(g, dy, w, dc, B, Cout, Cin, nullptr, nullptr, 0, (char*)ws + cls[k].ws_off, label, st,
+                                  w_ready != 0);
                 continue;
             }
             int64_t nw = (int64_t)Cin * K;
@@ -249,5 +283,78 @@ extern "C" int scat_conv2d_dgrad_s2(const float* dy, const float* w, float* dx, 
         }
     }
     SCAT_LAUNCH_CHECK("scat_conv2d_dgrad_s2");
+    return SCAT_OK;
+}
+
+// ---------------------------------------------------------------- prepared weights
+//
+// Every split-operand convolution re-lays its weights (three bf16 planes, MFMA operand order) before its main
+// kernel: one small launch per convolution and direction, 114 per ResNet-50 step.  A caller that keeps one
+// persistent workspace per (weight, direction) can instead describe all of them once (scat_wprep_jobs, host side),
+// upload the table, re-lay the whole network with ONE launch after each weight update (scat_wprep_run) and pass
+// w_ready = 1 to the convolution entry points.  The library keeps no state: table and workspaces are the caller's.
+extern "C" int64_t scat_wprep_job_bytes(void) { return (int64_t)sizeof(WPrepJob); }
+
+extern "C" int64_t scat_wprep_jobs(int kind, const float* w, void* ws, int64_t ws_bytes, int Cout, int Cin, int KH,
+                                   int KW, int pad, int64_t blk0, void* jobs_out, int max_jobs, int* njobs_out) {
+    if (!w || !ws || !jobs_out || !njobs_out || Cout <= 0 || Cin <= 0 || max_jobs < 4 || ((uintptr_t)ws & 15)) {
+        set_error("scat_wprep_jobs: bad argument");
+        return SCAT_E_ARG;
+    }
+    WPrepJob jobs[4];
+    int n = 1;
+    int64_t need = 0;
+    switch (kind) {
+        case SCAT_WPREP_CONV1X1_FWD:
+            jobs[0] = wprep_job(w, ws, Cout, Cin, 0, 1, 1, 1, 1, 0, 0, 1);
+            need = taps_split_ws(Cout, Cin, 1);
+            break;
+        case SCAT_WPREP_CONV1X1_DGRAD:
+            jobs[0] = wprep_job(w, ws, Cin, Cout, 1, 1, 1, 1, 1, 0, 0, 1);
+            need = taps_split_ws(Cin, Cout, 1);
+            break;
+        case SCAT_WPREP_CONV3X3_FWD:
+            jobs[0] = wprep_job(w, ws, Cout, Cin, 0, 3, 3, 9, 3, 0, 0, 1);
+            need = taps_split_ws(Cout, Cin, 9);
+            break;
+        case SCAT_WPREP_CONV3X3_DGRAD:
+            jobs[0] = wprep_job(w, ws, Cin, Cout, 1, 3, 3, 9, 3, 0, 0, 1);
+            need = taps_split_ws(Cin, Cout, 9);
+            break;
+        case SCAT_WPREP_FWD_SPLIT:
+            jobs[0] = wprep_job(w, ws, Cout, Cin, 0, KH, KW, KH * KW, KW, 0, 0, 1);
+            need = taps_split_ws(Cout, Cin, KH * KW);
+            break;
+        case SCAT_WPREP_DGRAD_S2:
+            n = dgrad_s2_wprep_jobs(w, ws, Cin, Cout, KH, KW, pad, jobs);
+            need = taps_split_ws(Cin, Cout, KH * KW);
+            break;
+        default:
+            set_error("scat_wprep_jobs: unknown kind %d", kind);
+            return SCAT_E_ARG;
+    }
+    if (ws_bytes < need) {
+        set_error("scat_wprep_jobs: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+        return SCAT_E_WORKSPACE;
+    }
+    int64_t b = blk0;
+    for (int k = 0; k < n; ++k) {
+        if (b + jobs[k].nblk > 0x7fffffffll) {
+            set_error("scat_wprep_jobs: table exceeds 2^31 blocks");
+            return SCAT_E_SHAPE;
+        }
+        jobs[k].blk0 = (int)b;
+        b += jobs[k].nblk;
+    }
+    memcpy(jobs_out, jobs, sizeof(WPrepJob) * n);
+    *njobs_out = n;
+    return b;      // first free block after these jobs
+}
+
+extern "C" int scat_wprep_run(const void* jobs_dev, int njobs, int64_t nblocks, void* stream) {
+    SCAT_REQUIRE(jobs_dev && njobs > 0 && nblocks > 0 && nblocks <= 0x7fffffffll, SCAT_E_ARG,
+                 "scat_wprep_run: bad argument");
+    wprep_batch_launch((const WPrepJob*)jobs_dev, njobs, (int)nblocks, (hipStream_t)stream);
+    SCAT_LAUNCH_CHECK("scat_wprep_run");
     return SCAT_OK;
 }

@@ -461,29 +461,65 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
 
 // ws[tap][ch][plane][i][16 bf16]: the three bf16 terms of element (i, c, tap).  w is the conv weight
 // [Cout][Cin][KH][KW]; forward: (i, c) = (co, ci); transposed (data gradient): (i, c) = (ci, co).  Tap t of the ntap
-// listed ones is (kh0 + ts*(t / KWt), kw0 + ts*(t % KWt)).
-__global__ void w_taps_split_kernel(const float* __restrict__ w, uint16_t* __restrict__ ws, int M, int C, int transposed,
-                                    int KH, int KW, int ntap, int KWt, int kh0, int kw0, int ts) {
-    const int nchunk = (C + 15) / 16;
-    const int64_t n = (int64_t)ntap * nchunk * M * 16;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        const int k16 = e & 15;
-        int64_t r = e >> 4;
-        const int i = r % M;
-        r /= M;                                          // r = tap * nchunk + ch
-        const int ch = r % nchunk, t = r / nchunk;
-        const int c = ch * 16 + k16;
-        const int kh = kh0 + ts * (t / KWt), kw = kw0 + ts * (t % KWt);
-        const int64_t pair = transposed ? (int64_t)c * M + i : (int64_t)i * C + c;
-        const float v = c < C ? w[(pair * KH + kh) * KW + kw] : 0.f;
-        uint32_t hi, mid, lo;
-        split3(v, 0.f, hi, mid, lo);
-        const int64_t base = (r * 3 * M + i) * 16 + k16;
-        ws[base] = (uint16_t)hi;
-        ws[base + (int64_t)M * 16] = (uint16_t)mid;
-        ws[base + (int64_t)2 * M * 16] = (uint16_t)lo;
-    }
+// listed ones is (kh0 + ts*(t / KWt), kw0 + ts*(t % KWt)).  (WPrepJob in conv_common.h.)
+__device__ __forceinline__ void wprep_element(const WPrepJob& j, int64_t e) {
+    const int nchunk = (j.C + 15) / 16;
+    const int k16 = e & 15;
+    int64_t r = e >> 4;
+    const int i = r % j.M;
+    r /= j.M;                                            // r = tap * nchunk + ch
+    const int ch = r % nchunk, t = r / nchunk;
+    const int c = ch * 16 + k16;
+    const int kh = j.kh0 + j.ts * (t / j.KWt), kw = j.kw0 + j.ts * (t % j.KWt);
+    const int64_t pair = j.transposed ? (int64_t)c * j.M + i : (int64_t)i * j.C + c;
+    const float v = c < j.C ? j.w[(pair * j.KH + kh) * j.KW + kw] : 0.f;
+    uint32_t hi, mid, lo;
+    split3(v, 0.f, hi, mid, lo);
+    const int64_t base = (r * 3 * j.M + i) * 16 + k16;
+    j.dst[base] = (uint16_t)hi;
+    j.dst[base + (int64_t)j.M * 16] = (uint16_t)mid;
+    j.dst[base + (int64_t)2 * j.M * 16] = (uint16_t)lo;
 }
+static inline int64_t wprep_elements(const WPrepJob& j) { return (int64_t)j.ntap * ((j.C + 15) / 16) * j.M * 16; }
+
+__global__ __launch_bounds__(256) void w_taps_split_kernel(WPrepJob j) {
+    const int64_t n = (int64_t)j.ntap * ((j.C + 15) / 16) * j.M * 16;
+    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n; e += gridDim.x * 256ll) wprep_element(j, e);
+}
+
+// the same for a table of jobs (device memory, sorted by blk0): block b belongs to the last job with blk0 <= b
+__global__ __launch_bounds__(256) void w_prep_batch_kernel(const WPrepJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const WPrepJob j = jobs[lo];
+    const int64_t n = (int64_t)j.ntap * ((j.C + 15) / 16) * j.M * 16;
+    const int64_t e = (int64_t)(b - j.blk0) * 256 + threadIdx.x;
+    if (e < n) wprep_element(j, e);
+}
+
+WPrepJob wprep_job(const float* w, void* dst, int M, int C, int transposed, int KH, int KW, int ntap, int KWt, int kh0,
+                   int kw0, int ts) {
+    WPrepJob j{};
+    j.w = w; j.dst = (uint16_t*)dst; j.M = M; j.C = C; j.transposed = transposed; j.KH = KH; j.KW = KW; j.ntap = ntap;
+    j.KWt = KWt; j.kh0 = kh0; j.kw0 = kw0; j.ts = ts;
+    j.blk0 = 0;
+    j.nblk = (int)((wprep_elements(j) + 255) / 256);
+    return j;
+}
+
+void wprep_batch_launch(const WPrepJob* jobs_dev, int njobs, int nblocks, hipStream_t st) {
+    hipLaunchKernelGGL(w_prep_batch_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs);
+}
+
+void wprep_launch(const WPrepJob& j, hipStream_t st) {
+    hipLaunchKernelGGL(w_taps_split_kernel, dim3(j.nblk < 2048 ? j.nblk : 2048), dim3(256), 0, st, j);
+}
+
 // fp32 transpose for the fp32-MFMA twin: ws[i][c] = w[c][i]
 __global__ void w1x1_t_kernel(const float* __restrict__ w, float* __restrict__ ws, int M, int C) {
     const int64_t n = (int64_t)M * C;
@@ -523,7 +559,7 @@ int64_t taps_split_ws(int M, int C, int ntap) { return (int64_t)ntap * M * ((C +
 
 void taps_split_launch(const TapsGeom& g, const float* src, const float* w, const OutDesc& dc, int B, int C, int M,
                        const float* in_scale, const float* in_shift, int in_relu, void* ws, const char* label,
-                       hipStream_t st) {
+                       hipStream_t st, bool w_ready) {
     PwDesc d{};
     d.src = src; d.scale = in_scale; d.shift = in_shift; d.relu = in_scale ? in_relu : 0;
     d.C = C; d.M = M; d.HW = g.H * g.W; d.npix = B * g.OH * g.OW; d.dHW = FastDiv::make(d.HW);
@@ -532,9 +568,8 @@ void taps_split_launch(const TapsGeom& g, const float* src, const float* w, cons
     d.nsrc = (int64_t)B * C * d.HW;
     d.variant = tuning();
     const int64_t nel = (int64_t)d.ntap * M * ((C + 15) / 16 * 16);
-    const int rblocks = (int)((nel + 255) / 256 < 2048 ? (nel + 255) / 256 : 2048);
-    hipLaunchKernelGGL(w_taps_split_kernel, dim3(rblocks), dim3(256), 0, st, w, (uint16_t*)ws, M, C, g.transposed, g.KH,
-                       g.KW, d.ntap, g.KWt, g.kh0, g.kw0, g.ts);
+    if (!w_ready)
+        wprep_launch(wprep_job(w, ws, M, C, g.transposed, g.KH, g.KW, d.ntap, g.KWt, g.kh0, g.kw0, g.ts), st);
     d.w = (const float*)ws;
     d.nw = (nel * 6 + 3) / 4;
     int cfg = M > 64 ? 0 : 1;
@@ -566,7 +601,8 @@ extern "C" int64_t scat_conv2d_fwd_split_ws(int Cout, int Cin, int KH, int KW) {
 // Cin % 16 == 0.  Used for the stride-2 convolutions (3x3/s1 has the halo kernel, 1x1/s1 scat_conv1x1_s1).
 extern "C" int scat_conv2d_fwd_split(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H,
                                      int W, int Cout, int KH, int KW, int stride, int pad, const float* in_scale,
-                                     const float* in_shift, int in_relu, void* ws, int64_t ws_bytes, void* stream) {
+                                     const float* in_shift, int in_relu, void* ws, int64_t ws_bytes, int w_ready,
+                                     void* stream) {
     int OH, OW;
     if (int e = check_geom("scat_conv2d_fwd_split", B, Cin, H, W, Cout, KH, KW, stride, pad, &OH, &OW)) return e;
     SCAT_REQUIRE(x && w && y, SCAT_E_ARG, "scat_conv2d_fwd_split: null pointer");
@@ -583,7 +619,8 @@ extern "C" int scat_conv2d_fwd_split(const float* x, const float* w, const float
     dc.dHW = FastDiv::make(OH * OW); dc.bias = bias; dc.bias_mode = bias ? 1 : 0; dc.n = (int64_t)B * Cout * OH * OW;
     char label[32];
     snprintf(label, sizeof label, "conv%dx%d_s%d", KH, KW, stride);
-    taps_split_launch(g, x, w, dc, B, Cin, Cout, in_scale, in_shift, in_relu, ws, label, (hipStream_t)stream);
+    taps_split_launch(g, x, w, dc, B, Cin, Cout, in_scale, in_shift, in_relu, ws, label, (hipStream_t)stream,
+                      w_ready != 0);
     SCAT_LAUNCH_CHECK("scat_conv2d_fwd_split");
     return SCAT_OK;
 }
@@ -594,7 +631,7 @@ extern "C" int scat_conv2d_fwd_split(const float* x, const float* w, const float
 // Split-operand products only; Cout % 16 == 0.  ws: scat_conv1x1_s1_ws(Cin, Cout) bytes.
 extern "C" int scat_conv1x1_s1_bnb(const float* g, const float* z, const float* coef3, const float* w, float* dx, int B,
                                    int Cin, int HW, int Cout, int accumulate, void* ws, int64_t ws_bytes,
-                                   void* stream) {
+                                   int w_ready, void* stream) {
     SCAT_REQUIRE(g && z && coef3 && w && dx, SCAT_E_ARG, "scat_conv1x1_s1_bnb: null pointer");
     SCAT_REQUIRE(math_mode() == 1, SCAT_E_ARG, "scat_conv1x1_s1_bnb: needs the split-operand product mode");
     SCAT_REQUIRE(B > 0 && Cin > 0 && HW > 0 && Cout > 0 && Cout % 16 == 0, SCAT_E_SHAPE,
@@ -613,7 +650,7 @@ extern "C" int scat_conv1x1_s1_bnb(const float* g, const float* z, const float* 
     d.nsrc = (int64_t)B * C * HW; d.variant = tuning();
     const int64_t nel = (int64_t)M * ((C + 15) / 16 * 16);
     const int rblocks = (int)((nel + 255) / 256 < 2048 ? (nel + 255) / 256 : 2048);
-    hipLaunchKernelGGL(w_taps_split_kernel, dim3(rblocks), dim3(256), 0, st, w, (uint16_t*)ws, M, C, 1, 1, 1, 1, 1, 0, 0, 1);
+    if (!w_ready) wprep_launch(wprep_job(w, ws, M, C, 1, 1, 1, 1, 1, 0, 0, 1), st);
     d.w = (const float*)ws;
     d.nw = (nel * 6 + 3) / 4;
     OutDesc dc{};
@@ -636,8 +673,9 @@ extern "C" int64_t scat_conv1x1_s1_ws(int M, int C) { return (int64_t)M * ((C + 
 // Needs C % 16 == 0 and 16-B aligned w/src; callers fall back to scat_conv2d_fwd / scat_conv2d_dgrad otherwise.
 extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int B, int C, int HW, int M,
                                int transposed, const float* bias, const float* in_scale, const float* in_shift,
-                               int in_relu, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+                               int in_relu, int accumulate, void* ws, int64_t ws_bytes, int w_ready, void* stream) {
     SCAT_REQUIRE(src && w && dst, SCAT_E_ARG, "scat_conv1x1_s1: null pointer");
+    SCAT_REQUIRE(!w_ready || math_mode() == 1, SCAT_E_ARG, "scat_conv1x1_s1: prepared weights exist for split products only");
     SCAT_REQUIRE(ws && ws_bytes >= scat_conv1x1_s1_ws(M, C), SCAT_E_WORKSPACE, "scat_conv1x1_s1: workspace too small");
     const float* a = w;
     SCAT_REQUIRE(B > 0 && C > 0 && HW > 0 && M > 0, SCAT_E_SHAPE, "scat_conv1x1_s1: non-positive dimension");
@@ -667,8 +705,7 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
     const int64_t nel = (int64_t)M * ((C + 15) / 16 * 16);
     const int rblocks = (int)((nel + 255) / 256 < 2048 ? (nel + 255) / 256 : 2048);
     if (math_mode() == 1) {
-        hipLaunchKernelGGL(w_taps_split_kernel, dim3(rblocks), dim3(256), 0, st, w, (uint16_t*)ws, M, C, transposed, 1, 1,
-                           1, 1, 0, 0, 1);
+        if (!w_ready) wprep_launch(wprep_job(w, ws, M, C, transposed, 1, 1, 1, 1, 0, 0, 1), st);
         d.w = (const float*)ws;
         d.nw = (nel * 6 + 3) / 4;
         if (!(tuning() >= 1 && tuning() <= 3)) cfg = M > 64 ? 0 : 1;   // measured at batch 96: 64x64 never wins

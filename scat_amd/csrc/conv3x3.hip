@@ -428,29 +428,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_split_kernel(HaloDesc d, OutDes
     store_tile<1, NI, BM, HB_N, WM, WN>(acc, dc, d.M, d.npix, i0, j0, 0);
 }
 
-// wt[t][ch][plane][i][16 bf16]: the three bf16 terms of element (t, i, c) = transposed ? w[c][i][t] : w[i][c][t]
-__global__ void wt3x3_split_kernel(const float* __restrict__ w, uint16_t* __restrict__ wt, int Cout, int Cin,
-                                   int transposed) {
-    const int I = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
-    const int nchunk = (K + 15) / 16;
-    const int64_t n = (int64_t)9 * nchunk * I * 16;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        const int k16 = e & 15;
-        int64_t r = e >> 4;
-        const int i = r % I;
-        r /= I;                                          // r = t * nchunk + ch
-        const int c = (int)(r % nchunk) * 16 + k16;
-        const int t = r / nchunk;
-        const int co = transposed ? c : i, ci = transposed ? i : c;
-        const float v = c < K ? w[((int64_t)co * Cin + ci) * 9 + t] : 0.f;
-        uint32_t hi, mid, lo;
-        split3(v, 0.f, hi, mid, lo);
-        const int64_t base = (r * 3 * I + i) * 16 + k16;
-        wt[base] = (uint16_t)hi;
-        wt[base + (int64_t)I * 16] = (uint16_t)mid;
-        wt[base + (int64_t)2 * I * 16] = (uint16_t)lo;
-    }
-}
+// (split-operand weights: wt[t][ch][plane][i][16 bf16], the shared re-layout of conv_common.h's WPrepJob with 9 taps)
 
 template <int WM, int HB_N, bool TF>
 static void launch_split(const HaloDesc& d, const OutDesc& dc, hipStream_t st) {
@@ -483,7 +461,7 @@ extern "C" int64_t scat_conv3x3_s1_ws(int Cout, int Cin) {
 // w is always the forward weight [Cout][Cin][3][3].
 extern "C" int scat_conv3x3_s1(const float* src, const float* w, float* dst, int B, int Cin, int H, int W, int Cout,
                                int transposed, const float* in_scale, const float* in_shift, int in_relu,
-                               int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+                               int accumulate, void* ws, int64_t ws_bytes, int w_ready, void* stream) {
     int OH, OW;
     if (int e = check_geom("scat_conv3x3_s1", B, Cin, H, W, Cout, 3, 3, 1, 1, &OH, &OW)) return e;
     SCAT_REQUIRE(src && w && dst, SCAT_E_ARG, "scat_conv3x3_s1: null pointer");
@@ -499,9 +477,10 @@ extern "C" int scat_conv3x3_s1(const float* src, const float* w, float* dst, int
     const bool split = math_mode() == 1;
     const int64_t nw = (int64_t)9 * ((Csrc + 15) / 16) * Cdst * 16;
     const int blocks = (int)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048);
-    if (split)
-        hipLaunchKernelGGL(wt3x3_split_kernel, dim3(blocks), dim3(256), 0, st, w, (uint16_t*)ws, Cout, Cin, transposed);
-    else
+    SCAT_REQUIRE(!w_ready || split, SCAT_E_ARG, "scat_conv3x3_s1: prepared weights exist for split products only");
+    if (split) {
+        if (!w_ready) wprep_launch(wprep_job(w, ws, Cdst, Csrc, transposed, 3, 3, 9, 3, 0, 0, 1), st);
+    } else
         hipLaunchKernelGGL(wt3x3_kernel, dim3(blocks), dim3(256), 0, st, w, (float*)ws, Cout, Cin, transposed);
 
     HaloDesc d{};

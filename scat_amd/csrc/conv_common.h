@@ -29,9 +29,27 @@ struct TapsGeom {
     int KH, KW, kh0, kw0, ts, transposed;   // which weights: (kh0 + ts*th, kw0 + ts*tw) of w[Cout][Cin][KH][KW]
 };
 int64_t taps_split_ws(int M, int C, int ntap);
+// w_ready: ws already holds this call's re-laid weights (scat_wprep_run), skip the re-layout launch
 void taps_split_launch(const TapsGeom& g, const float* src, const float* w, const OutDesc& dc, int B, int C, int M,
                        const float* in_scale, const float* in_shift, int in_relu, void* ws, const char* label,
-                       hipStream_t st);
+                       hipStream_t st, bool w_ready = false);
+
+// One weight re-layout for the split-operand kernels: dst[tap][chunk][plane][i][16 bf16] = the three bf16 terms of
+// element (i, c) of tap (kh0 + ts*(t / KWt), kw0 + ts*(t % KWt)) of w[Cout][Cin][KH][KW]; (i, c) = (co, ci), or
+// (ci, co) when transposed.  Every split kernel's weight operand is one or more of these (wprep_launch: one job, one
+// launch; scat_wprep_run: a table of jobs, one launch for a whole network).
+struct WPrepJob {
+    const float* w;
+    uint16_t* dst;
+    int M, C, transposed, KH, KW, ntap, KWt, kh0, kw0, ts;
+    int blk0, nblk;    // 256-element blocks [blk0, blk0 + nblk) of the batched launch
+};
+WPrepJob wprep_job(const float* w, void* dst, int M, int C, int transposed, int KH, int KW, int ntap, int KWt, int kh0,
+                   int kw0, int ts);
+void wprep_launch(const WPrepJob& j, hipStream_t st);
+void wprep_batch_launch(const WPrepJob* jobs_dev, int njobs, int nblocks, hipStream_t st);
+// jobs of scat_conv2d_dgrad_s2's parity classes (each class has its own slice of ws); returns their number
+int dgrad_s2_wprep_jobs(const float* w, void* ws, int Cin, int Cout, int KH, int KW, int pad, WPrepJob* out);
 
 // split-operand weight gradient (conv_wgrad_split.hip): 1x1/pad 0 and 3x3/pad 1, stride 1
 struct WgSplitPlan {
@@ -43,5 +61,7 @@ void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, f
                         hipStream_t st, const float* dy2 = nullptr, const float* coef3 = nullptr);
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int splits,
                                      int accumulate);
+// out[e] (+)= sum over slabs, fixed order (vectorised / slab-parallel when n % 4 == 0)
+void launch_splitk_reduce(const float* slab, float* out, int64_t n, int splits, int accumulate, hipStream_t st);
 
 }  // namespace scat

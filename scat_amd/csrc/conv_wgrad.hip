@@ -21,6 +21,77 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
     }
 }
 
+// The same sum for n % 4 == 0, 16 bytes per lane.  A workgroup owns 256 consecutive elements; its WAVES wavefronts
+// take consecutive ranges of the slabs (a small output with hundreds of slabs — layer1's 64x64 — would otherwise be a
+// few wavefronts walking the whole stack at one memory latency per 8 slabs) and their partial sums are combined
+// through LDS in wavefront order: the result depends on (splits, WAVES) only, never on timing.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void splitk_reduce4_kernel(const float4* __restrict__ slab,
+                                                                    float4* __restrict__ out, int64_t n4, int splits,
+                                                                    int accumulate) {
+    __shared__ float4 part[WAVES > 1 ? WAVES : 1][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t e = blockIdx.x * 64ll + lane;
+    const bool live = e < n4;
+    const int per = (splits + WAVES - 1) / WAVES;
+    const int z0 = wave * per, z1 = min(z0 + per, splits);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = slab[(int64_t)(z + q) * n4 + e];
+            s.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+            s.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+            s.z += ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
+            s.w += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
+        }
+        for (; z < z1; ++z) {
+            const float4 v = slab[(int64_t)z * n4 + e];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    if constexpr (WAVES > 1) {
+        part[wave][lane] = s;
+        __syncthreads();
+        if (wave != 0) return;
+        s = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            const float4 v = part[w][lane];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    if (!live) return;
+    if (accumulate) {
+        const float4 o = out[e];
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    out[e] = s;
+}
+
+void launch_splitk_reduce(const float* slab, float* out, int64_t n, int splits, int accumulate, hipStream_t st) {
+    static const int vec = [] { const char* e = getenv("SCAT_REDUCE_VEC"); return e ? atoi(e) : 1; }();
+    if (vec && n % 4 == 0 && (((uintptr_t)slab | (uintptr_t)out) & 15) == 0) {
+        const int64_t n4 = n / 4;
+        const dim3 grid((unsigned)((n4 + 63) / 64));
+        const float4* s4 = (const float4*)slab;
+        float4* o4 = (float4*)out;
+        // enough wavefronts to cover the chip (~2048) before giving a wavefront more than 8 slabs
+        const int64_t waves1 = (n4 + 63) / 64;
+        if (splits >= 64 && waves1 < 512)
+            hipLaunchKernelGGL(splitk_reduce4_kernel<16>, grid, dim3(1024), 0, st, s4, o4, n4, splits, accumulate);
+        else if (splits >= 16 && waves1 < 2048)
+            hipLaunchKernelGGL(splitk_reduce4_kernel<4>, grid, dim3(256), 0, st, s4, o4, n4, splits, accumulate);
+        else
+            hipLaunchKernelGGL(splitk_reduce4_kernel<1>, grid, dim3(64), 0, st, s4, o4, n4, splits, accumulate);
+        return;
+    }
+    const int blocks = (int)((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(64), 0, st, slab, out, n, splits, accumulate);
+}
+
 static int wgrad_splits(int M, int N, int K, int bm, int bn) {
     int tiles = cdiv(M, bm) * cdiv(N, bn);
     int s = cdiv(1024, tiles);                       // aim for ~4 workgroups per CU
@@ -118,8 +189,7 @@ extern "C" int scat_conv1x1_wgrad_bnb(const float* g, const float* z, const floa
     SCAT_LAUNCH_CHECK("scat_conv1x1_wgrad_bnb");
     if (q.splits > 1) {
         int64_t n = (int64_t)q.M * q.N;
-        int blocks = (int)((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(64), 0, st, (const float*)ws, dw, n, q.splits, 0);
+        launch_splitk_reduce((const float*)ws, dw, n, q.splits, 0, st);
         SCAT_LAUNCH_CHECK("scat_conv1x1_wgrad_bnb(reduce)");
     }
     return SCAT_OK;
@@ -149,8 +219,7 @@ extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int
         SCAT_LAUNCH_CHECK("scat_conv2d_wgrad");
         if (q.splits > 1) {
             int64_t n = (int64_t)q.M * q.N;
-            int blocks = (int)((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096);
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(64), 0, st2, (const float*)ws, dw, n, q.splits, 0);
+            launch_splitk_reduce((const float*)ws, dw, n, q.splits, 0, st2);
             SCAT_LAUNCH_CHECK("scat_conv2d_wgrad(reduce)");
         }
         return SCAT_OK;
@@ -187,8 +256,7 @@ extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int
     SCAT_LAUNCH_CHECK("scat_conv2d_wgrad");
     if (p.splits > 1) {
         int64_t n = (int64_t)p.M * p.N;
-        int blocks = (int)((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(64), 0, st, (const float*)ws, dw, n, p.splits, 0);
+        launch_splitk_reduce((const float*)ws, dw, n, p.splits, 0, st);
         SCAT_LAUNCH_CHECK("scat_conv2d_wgrad(reduce)");
     }
     return SCAT_OK;

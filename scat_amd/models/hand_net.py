@@ -49,6 +49,17 @@ class PositionalEncoding(nn.Module):
         return _TokensFn.apply(x, self.pe[0], None, None)
 
 
+def _upload_indices(idx, device):
+    """int32 index tensor on ``device`` without making the host wait: ``torch.tensor(list, device=cuda)`` copies from
+    pageable memory, which synchronises the stream — in the middle of the step (after the backbone forward) that
+    drains the launch queue and the many small kernels of the token path then run at host speed.  Staged through
+    the pinned caching allocator instead (the block is recycled only after the copy has completed)."""
+    h = torch.tensor(idx, dtype=torch.int32)
+    if torch.device(device).type != "cuda":
+        return h.to(device)
+    return h.pin_memory().to(device, non_blocking=True)
+
+
 class _TokensFn(torch.autograd.Function):
     """x + pe, then rows ``masked`` <- mask_token (models/hand_net.py:366-373), one pass."""
 
@@ -137,7 +148,7 @@ class EncoderTransformerHRNet(nn.Module):
             masked = list(range(128))
             random.shuffle(masked)
             masked = masked[: int(self.mask_rate * 128)]
-            midx = torch.tensor(masked, dtype=torch.int32, device=feat.device) if masked else None
+            midx = _upload_indices(masked, feat.device) if masked else None
         pe = self.positionalEncoding.pe[0] if self.pos_embed else None
         tokens = _TokensFn.apply(feat.view(B, 128, -1), pe, self.mask_token, midx)
         feat = snn.token_mean(self.transformer(tokens, None))                   # [B,196]
@@ -234,7 +245,7 @@ class EncoderTransformer(nn.Module):
         if t is None:
             if len(self._midx_cache) > 4096:
                 self._midx_cache.clear()
-            t = torch.tensor(masked, dtype=torch.int32, device=device)
+            t = _upload_indices(masked, device)
             self._midx_cache[key] = t
         return t
 

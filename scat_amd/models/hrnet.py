@@ -30,9 +30,10 @@ class _BasicBlockFn(torch.autograd.Function):
     def forward(ctx, x, blk, w1, g1, b1, w2, g2, b2):
         training = blk.training
         x = x if x.is_contiguous() else x.contiguous()
-        c1 = ops.conv2d_fwd(x, w1, 1, 1)
+        wp = getattr(blk, "_wprep", None)
+        c1 = ops.conv2d_fwd(x, w1, 1, 1, wp=wp)
         s1 = _rn._BNState(c1, blk.bn1, training)
-        c2 = ops.conv2d_fwd(c1, w2, 1, 1, s1.scale, s1.shift, True)
+        c2 = ops.conv2d_fwd(c1, w2, 1, 1, s1.scale, s1.shift, True, wp=wp)
         s2 = _rn._BNState(c2, blk.bn2, training)
         if _rn._NBT:
             torch._foreach_add_(_rn._NBT, 1)
@@ -55,11 +56,12 @@ class _BasicBlockFn(torch.autograd.Function):
         dc2, dg2, db2 = ops.bn_bwd(dout, c2, None if ctx.has_mask else m, True, s2.scale, s2.shift, s2.mean, s2.invstd,
                                    blk.bn2.weight, dres=g, y_mask=m if ctx.has_mask else None)
         dw2 = ops.conv2d_wgrad(dc2, c1, tuple(blk.conv2.weight.shape), 1, 1, s1.scale, s1.shift, True)
-        da1 = ops.conv2d_dgrad_w(dc2, blk.conv2.weight, tuple(c1.shape), 1, 1)
+        wp = getattr(blk, "_wprep", None)
+        da1 = ops.conv2d_dgrad_w(dc2, blk.conv2.weight, tuple(c1.shape), 1, 1, wp=wp)
         del dc2
         dc1, dg1, db1 = ops.bn_bwd(da1, c1, None, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight, dx=da1)
         dw1 = ops.conv2d_wgrad(dc1, x, tuple(blk.conv1.weight.shape), 1, 1)
-        dx = ops.conv2d_dgrad_w(dc1, blk.conv1.weight, tuple(x.shape), 1, 1, out=g, accumulate=True)
+        dx = ops.conv2d_dgrad_w(dc1, blk.conv1.weight, tuple(x.shape), 1, 1, out=g, accumulate=True, wp=wp)
         return dx, None, dw1, dg1, db1, dw2, dg2, db2
 
 
@@ -188,8 +190,15 @@ class HRNet(nn.Module):
                                           nn.Sequential(cbr(c * 4, c * 8, 2))])
         self.stage4 = nn.Sequential(StageModule(4, 4, c, m), StageModule(4, 4, c, m), StageModule(4, 1, c, m))
         self.final_layer = snn.Conv2d(c, nof_joints, kernel_size=(1, 1), stride=(1, 1))
+        # prepared weights: every convolution of the network shares one ops.WeightPrep, re-laid by ONE launch at the
+        # start of forward instead of 2 x 293 small ones spread over the step
+        object.__setattr__(self, "_wprep", ops.WeightPrep())
+        for m in self.modules():
+            if isinstance(m, (snn.Conv2d, BasicBlock)):
+                object.__setattr__(m, "_wprep", self._wprep)
 
     def forward(self, x):
+        self._wprep.run(self.training)
         x = self.relu(self.bn1(self.conv1(x)))
         x = self.relu(self.bn2(self.conv2(x)))
         x = self.layer1(x)

@@ -91,6 +91,8 @@ class _BackboneFn(torch.autograd.Function):
         x = x if x.is_contiguous() else x.contiguous()
         tape = []
         _NBT.clear()
+        wp = net._wprep
+        wp.run(training)       # one launch re-lays every convolution weight for this step (ops.WeightPrep)
         # stem: conv7x7/2 -> [BN -> ReLU -> maxpool fused]
         c0 = ops.conv2d_fwd(x, net.conv1.weight, 2, 3)
         s0 = _BNState(c0, net.bn1, training)
@@ -99,20 +101,20 @@ class _BackboneFn(torch.autograd.Function):
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
             for blk in layer:
                 xin = cur
-                c1 = ops.conv2d_fwd(xin, blk.conv1.weight, 1, 0)
+                c1 = ops.conv2d_fwd(xin, blk.conv1.weight, 1, 0, wp=wp)
                 s1 = _BNState(c1, blk.bn1, training)
-                c2 = ops.conv2d_fwd(c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True)
+                c2 = ops.conv2d_fwd(c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True, wp=wp)
                 s2 = _BNState(c2, blk.bn2, training)
-                c3 = ops.conv2d_fwd(c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True)
+                c3 = ops.conv2d_fwd(c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True, wp=wp)
                 s3 = _BNState(c3, blk.bn3, training)
                 if blk.downsample is not None:
                     # stride-2 shortcut: pack the pixels it reads once, then it (and its weight gradient) is a
                     # stride-1 pointwise convolution
                     xs = ops.subsample2(xin) if blk.stride == 2 and SUBSAMPLE else None
                     if xs is not None:
-                        cd = ops.conv2d_fwd(xs, blk.downsample[0].weight, 1, 0)
+                        cd = ops.conv2d_fwd(xs, blk.downsample[0].weight, 1, 0, wp=wp)
                     else:
-                        cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0)
+                        cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0, wp=wp)
                     sd = _BNState(cd, blk.downsample[1], training)
                     sd.xs = xs if training else None
                     res = ops.bn_apply(cd, sd.scale, sd.shift, None, False)
@@ -155,6 +157,7 @@ class _BackboneFn(torch.autograd.Function):
             raise RuntimeError("scat_amd: backbone backward needs a training-mode forward (BN batch statistics)")
         feat, *outs = ctx.saved_tensors
         (pooled,) = ctx.tail
+        wp = net._wprep            # data-gradient weights were re-laid with the forward ones at the start of the step
         tape = [tuple(outs[v] if isinstance(v, int) else v for v in rec) for rec in ctx.tape]
         sink = getattr(net, "_grad_sink", None)   # flat gradient buckets (scat_amd.dp.GradBuckets), or None
         grads = {}
@@ -240,19 +243,19 @@ class _BackboneFn(torch.autograd.Function):
                 put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
                 dw3, ev3 = wgrad_bnb(g, c3, coef3, c2, w3, s2.scale, s2.shift, True)   # g is overwritten further down
                 put(w3, dw3)
-                da2 = ops.conv1x1_dgrad_bnb(g, c3, coef3, w3, tuple(c2.shape))
+                da2 = ops.conv1x1_dgrad_bnb(g, c3, coef3, w3, tuple(c2.shape), wp=wp)
             else:
                 dc3, dg, db = ops.bn_bwd(dcur, c3, out, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
                                          gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), dres=dcur, y_mask=omask)
                 put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
                 put(w3, wgrad(dc3, c2, w3, 1, 0, s2.scale, s2.shift, True))
-                da2 = ops.conv2d_dgrad_w(dc3, w3, tuple(c2.shape), 1, 0)
+                da2 = ops.conv2d_dgrad_w(dc3, w3, tuple(c2.shape), 1, 0, wp=wp)
                 del dc3
             dc2, dg, db = ops.bn_bwd(da2, c2, None, True, s2.scale, s2.shift, s2.mean, s2.invstd, blk.bn2.weight,
                                      gbuf(blk.bn2.weight), gbuf(blk.bn2.bias), dx=da2)
             put(blk.bn2.weight, dg), put(blk.bn2.bias, db)
             put(blk.conv2.weight, wgrad(dc2, c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True))
-            da1 = ops.conv2d_dgrad_w(dc2, blk.conv2.weight, tuple(c1.shape), blk.stride, 1)
+            da1 = ops.conv2d_dgrad_w(dc2, blk.conv2.weight, tuple(c1.shape), blk.stride, 1, wp=wp)
             del dc2, da2
             w1 = blk.conv1.weight
             fold1 = use_bnb and BNB1 and (c1.shape[2] * c1.shape[3]) % 4 == 0 and w1.shape[0] % 16 == 0
@@ -278,14 +281,14 @@ class _BackboneFn(torch.autograd.Function):
                     put(dsw, wgrad(dcd, sd.xs, dsw, 1, 0))
                 else:
                     put(dsw, wgrad(dcd, xin, dsw, blk.stride, 0))
-                dxin = ops.conv2d_dgrad_w(dcd, dsw, tuple(xin.shape), blk.stride, 0)
+                dxin = ops.conv2d_dgrad_w(dcd, dsw, tuple(xin.shape), blk.stride, 0, wp=wp)
                 del dcd
             else:
                 dxin = g
             if fold1:
-                dcur = ops.conv1x1_dgrad_bnb(da1, c1, coef1, w1, tuple(xin.shape), out=dxin, accumulate=True)
+                dcur = ops.conv1x1_dgrad_bnb(da1, c1, coef1, w1, tuple(xin.shape), out=dxin, accumulate=True, wp=wp)
             else:
-                dcur = ops.conv2d_dgrad_w(dc1, w1, tuple(xin.shape), 1, 0, out=dxin, accumulate=True)
+                dcur = ops.conv2d_dgrad_w(dc1, w1, tuple(xin.shape), 1, 0, out=dxin, accumulate=True, wp=wp)
                 del dc1
             del da1, g
             remaining -= 1
@@ -333,6 +336,7 @@ class ResNet(nn.Module):
         self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
         self.avgpool = nn.Identity()
         self.fc1 = snn.Linear(512 * block.expansion, 1024)
+        self._wprep = ops.WeightPrep()   # prepared convolution weights (one re-layout launch per step)
         for m in self.modules():   # same initialisers as resnet.py:118-123
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")

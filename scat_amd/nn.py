@@ -21,11 +21,12 @@ class _Conv2dFn(torch.autograd.Function):
     """nn.Conv2d forward/backward (models/resnet.py:65-72; hand_net.py:329) on the MFMA engine."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad):
+    def forward(ctx, x, w, bias, stride, pad, wp=None):
         x, w = _c(x), _c(w)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, bias is not None)
-        return ops.conv2d_fwd(x, w, stride, pad, bias=bias)
+        ctx.wp = wp               # the owning network's ops.WeightPrep (prepared weights), or None
+        return ops.conv2d_fwd(x, w, stride, pad, bias=bias, wp=wp)
 
     @staticmethod
     def backward(ctx, dy):
@@ -34,13 +35,13 @@ class _Conv2dFn(torch.autograd.Function):
         dy = _c(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_dgrad_w(dy, w, tuple(x.shape), stride, pad)
+            dx = ops.conv2d_dgrad_w(dy, w, tuple(x.shape), stride, pad, wp=ctx.wp)
         if ctx.needs_input_grad[1]:
             dw = ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad)
         if has_bias and ctx.needs_input_grad[2]:
             B, C, H, W = dy.shape
             db = ops.colsum(_c(dy.permute(0, 2, 3, 1).reshape(-1, C)))
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class _LinearFn(torch.autograd.Function):
@@ -141,8 +142,8 @@ class _BatchNormFn(torch.autograd.Function):
                            "(eval.py runs forward only)")
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0):
-    return _Conv2dFn.apply(x, w, bias, stride, pad)
+def conv2d(x, w, bias=None, stride=1, pad=0, wp=None):
+    return _Conv2dFn.apply(x, w, bias, stride, pad, wp)
 
 
 def linear(x, w, bias=None):
@@ -153,7 +154,8 @@ class Conv2d(nn.Conv2d):
     def forward(self, x):
         assert self.kernel_size[0] == self.kernel_size[1] and self.stride[0] == self.stride[1]
         assert self.dilation == (1, 1) and self.groups == 1
-        return conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0])
+        # _wprep: set by a network that prepares all its convolution weights with one launch (HRNet)
+        return conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], getattr(self, "_wprep", None))
 
 
 class Linear(nn.Linear):

@@ -6,6 +6,7 @@ caller-owned buffers. There is no fallback path: tensors must be fp32, contiguou
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -58,6 +59,92 @@ def workspace(nbytes: int, device, slot: str = "default") -> torch.Tensor:
     return buf
 
 
+# kinds of scat_wprep_jobs (include/scat_hip.h SCAT_WPREP_*)
+WPREP_CONV1X1_FWD, WPREP_CONV1X1_DGRAD, WPREP_CONV3X3_FWD, WPREP_CONV3X3_DGRAD, WPREP_FWD_SPLIT, WPREP_DGRAD_S2 = range(6)
+WPREP = os.environ.get("SCAT_WPREP", "1") != "0"   # 0: every convolution re-lays its weights itself (A/B runs)
+
+
+class WeightPrep:
+    """Prepared weights of one network (include/scat_hip.h "prepared weights"): one persistent workspace per
+    (weight, kind) and a device table of their re-layout jobs, so that the 2 x 53 small per-convolution launches of a
+    ResNet-50 step become ONE launch at the start of the step.
+
+    Entries register themselves the first time a convolution is called with this object as ``wp`` (that call still
+    re-lays its own weights, into the persistent workspace); ``run()`` — called by the network at the start of its
+    forward — re-lays every registered weight with one launch and marks the entries ready.  Between a weight update
+    and the next ``run()`` the workspaces are stale, hence the contract: the owner calls ``run()`` first thing in
+    every forward (training: always; inference: when a weight's version counter moved or a training forward
+    happened since)."""
+
+    def __init__(self):
+        self.entries = {}          # (data_ptr, kind) -> [dims, buf, ready, weight]
+        self.table = None          # (device uint8 tensor, njobs, nblocks)
+        self.dirty = True          # weights may have changed since the last run()
+        self.versions = None
+
+    def __deepcopy__(self, memo):
+        return WeightPrep()     # workspaces are keyed by the original parameters' addresses
+
+    def slot(self, w, kind, Cout, Cin, KH, KW, pad, nbytes):
+        """-> (workspace, w_ready) for this weight and kind; registers the pair on first use"""
+        key = (w.data_ptr(), kind)
+        dims = (Cout, Cin, KH, KW, pad, int(nbytes))
+        e = self.entries.get(key)
+        if e is None or e[0] != dims or e[1].device != w.device:
+            e = [dims, torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=w.device), False, w]
+            self.entries[key] = e
+            self.table = None
+        return e[1], int(e[2])
+
+    def _build(self):
+        L = lib()
+        jb = int(L.scat_wprep_job_bytes())
+        host = ctypes.create_string_buffer(4 * jb)
+        nj = ctypes.c_int(0)
+        blobs, blk = [], 0
+        for (ptr, kind), e in self.entries.items():
+            Cout, Cin, KH, KW, pad, nbytes = e[0]
+            blk = L.scat_wprep_jobs(kind, ptr, _p(e[1]), e[1].numel(), Cout, Cin, KH, KW, pad, blk, host, 4,
+                                    ctypes.byref(nj))
+            if blk < 0:
+                raise RuntimeError(f"scat_wprep_jobs failed ({blk}): {L.scat_last_error().decode(errors='replace')}")
+            blobs.append(host.raw[: nj.value * jb])
+        raw = b"".join(blobs)
+        dev = next(iter(self.entries.values()))[1].device
+        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.table = (t, len(raw) // jb, blk)
+
+    def run(self, training):
+        """re-lay every registered weight (one launch) if they may have changed; no-op outside split-product mode"""
+        if not self.entries or not WPREP or lib().scat_get_math_mode() != 1:
+            for e in self.entries.values():
+                e[2] = False
+            return
+        dead = [k for k, e in self.entries.items() if e[3].data_ptr() != k[0]]   # the parameter moved (.to(), .cuda())
+        for k in dead:
+            del self.entries[k]
+            self.table = None
+        if not self.entries:
+            return
+        ver = sum(e[3]._version for e in self.entries.values())
+        stale = training or self.dirty or ver != self.versions or self.table is None
+        if self.table is None:
+            self._build()
+        if stale:
+            t, nj, nblk = self.table
+            lib().scat_wprep_run(_p(t), nj, nblk, _stream())
+            for e in self.entries.values():
+                e[2] = True
+        self.versions = ver
+        self.dirty = bool(training)       # a training forward is followed by a weight update we do not see
+
+
+def _wp_ws(wp, w, kind, Cout, Cin, KH, KW, pad, nbytes, device):
+    if wp is not None and WPREP and lib().scat_get_math_mode() == 1:
+        return wp.slot(w, kind, Cout, Cin, KH, KW, pad, nbytes)
+    return workspace(nbytes, device, "wt"), 0
+
+
 def set_math_mode(mode: int) -> int:
     """0: fp32 MFMA products; 1: fp32 operands as three bf16 terms, six bf16 MFMA products, fp32 accumulate
     (include/scat_hip.h).  Returns the previous mode."""
@@ -96,28 +183,30 @@ def _pw_ok(KH, KW, stride, pad, csrc, *ts):
             and all(t is None or t.data_ptr() % 16 == 0 for t in ts))
 
 
-def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, bias=None, out=None):
+def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, bias=None, out=None, wp=None):
+    """wp: the network's WeightPrep (prepared weights), or None: the call re-lays its weights itself"""
     _chk(x, w, in_scale, in_shift, bias)
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
     OH, OW = conv_out_hw(H, W, KH, stride, pad)
     y = out if out is not None else torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
     if _pw_ok(KH, KW, stride, pad, Cin, x, w, in_scale, in_shift):
-        ws = workspace(lib().scat_conv1x1_s1_ws(Cout, Cin), x.device, "wt")
+        ws, rdy = _wp_ws(wp, w, WPREP_CONV1X1_FWD, Cout, Cin, 1, 1, 0, lib().scat_conv1x1_s1_ws(Cout, Cin), x.device)
         _prof(2.0 * B * OH * OW * Cout * Cin, lib().scat_conv1x1_s1, _p(x), _p(w), _p(y), B, Cin, H * W, Cout, 0,
-              _p(bias), _p(in_scale), _p(in_shift), int(in_relu), 0, _p(ws), ws.numel(), _stream())
+              _p(bias), _p(in_scale), _p(in_shift), int(in_relu), 0, _p(ws), ws.numel(), rdy, _stream())
         return y
     if (stride == 2 and KH in (1, 3) and KW == KH and Cin % 16 == 0 and lib().scat_get_math_mode() == 1
             and os.environ.get("SCAT_S2_SPLIT", "1") != "0"):
-        ws = workspace(lib().scat_conv2d_fwd_split_ws(Cout, Cin, KH, KW), x.device, "wt")
+        ws, rdy = _wp_ws(wp, w, WPREP_FWD_SPLIT, Cout, Cin, KH, KW, pad,
+                         lib().scat_conv2d_fwd_split_ws(Cout, Cin, KH, KW), x.device)
         _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_fwd_split, _p(x), _p(w), _p(bias), _p(y), B,
               Cin, H, W, Cout, KH, KW, stride, pad, _p(in_scale), _p(in_shift), int(in_relu), _p(ws), ws.numel(),
-              _stream())
+              rdy, _stream())
         return y
     if _halo_ok(KH, KW, stride, pad, Cin, W) and bias is None:
-        ws = workspace(lib().scat_conv3x3_s1_ws(Cout, Cin), x.device, "wt")
+        ws, rdy = _wp_ws(wp, w, WPREP_CONV3X3_FWD, Cout, Cin, 3, 3, 1, lib().scat_conv3x3_s1_ws(Cout, Cin), x.device)
         _prof(2.0 * B * OH * OW * Cout * Cin * 9, lib().scat_conv3x3_s1, _p(x), _p(w), _p(y), B, Cin, H, W, Cout, 0,
-              _p(in_scale), _p(in_shift), int(in_relu), 0, _p(ws), ws.numel(), _stream())
+              _p(in_scale), _p(in_shift), int(in_relu), 0, _p(ws), ws.numel(), rdy, _stream())
         return y
     _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_fwd, _p(x), _p(w), _p(bias), _p(y), B, Cin, H, W,
           Cout, KH, KW, stride, pad, _p(in_scale), _p(in_shift), int(in_relu), _stream())
@@ -143,7 +232,7 @@ def conv2d_dgrad(dy, wt, x_shape, w_shape, stride, pad, out=None, accumulate=Fal
     return dx
 
 
-def conv2d_dgrad_w(dy, w, x_shape, stride, pad, out=None, accumulate=False):
+def conv2d_dgrad_w(dy, w, x_shape, stride, pad, out=None, accumulate=False, wp=None):
     """Data gradient from the ORIGINAL weights: picks the parity-decomposed stride-2 kernels when they apply,
     else transposes the weights and runs the generic gather."""
     _chk(dy, w, out)
@@ -151,22 +240,26 @@ def conv2d_dgrad_w(dy, w, x_shape, stride, pad, out=None, accumulate=False):
     Cout, _, KH, KW = w.shape
     if stride == 2 and ((KH == 1 and pad == 0) or (KH == 3 and pad == 1)) and Cout % 4 == 0:
         dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
-        ws = workspace(lib().scat_conv2d_dgrad_s2_ws(Cin, Cout, KH, KW), dy.device, "wt")
+        need = lib().scat_conv2d_dgrad_s2_ws(Cin, Cout, KH, KW)
+        if Cout % 16 == 0:      # (the split-operand classes; otherwise the fp32 engine re-lays per class)
+            ws, rdy = _wp_ws(wp, w, WPREP_DGRAD_S2, Cout, Cin, KH, KW, pad, need, dy.device)
+        else:
+            ws, rdy = workspace(need, dy.device, "wt"), 0
         OH, OW = conv_out_hw(H, W, KH, stride, pad)
         _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_dgrad_s2, _p(dy), _p(w), _p(dx), B, Cin, H,
-              W, Cout, KH, KW, pad, int(accumulate), _p(ws), ws.numel(), _stream())
+              W, Cout, KH, KW, pad, int(accumulate), _p(ws), ws.numel(), rdy, _stream())
         return dx
     if _halo_ok(KH, KW, stride, pad, Cout, W):
         dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
-        ws = workspace(lib().scat_conv3x3_s1_ws(Cout, Cin), dy.device, "wt")
+        ws, rdy = _wp_ws(wp, w, WPREP_CONV3X3_DGRAD, Cout, Cin, 3, 3, 1, lib().scat_conv3x3_s1_ws(Cout, Cin), dy.device)
         _prof(2.0 * B * H * W * Cout * Cin * 9, lib().scat_conv3x3_s1, _p(dy), _p(w), _p(dx), B, Cin, H, W, Cout, 1,
-              0, 0, 0, int(accumulate), _p(ws), ws.numel(), _stream())
+              0, 0, 0, int(accumulate), _p(ws), ws.numel(), rdy, _stream())
         return dx
     if _pw_ok(KH, KW, stride, pad, Cout, dy, w, out):
         dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
-        ws = workspace(lib().scat_conv1x1_s1_ws(Cin, Cout), dy.device, "wt")
+        ws, rdy = _wp_ws(wp, w, WPREP_CONV1X1_DGRAD, Cout, Cin, 1, 1, 0, lib().scat_conv1x1_s1_ws(Cin, Cout), dy.device)
         _prof(2.0 * B * H * W * Cout * Cin, lib().scat_conv1x1_s1, _p(dy), _p(w), _p(dx), B, Cout, H * W, Cin, 1, 0, 0,
-              0, 0, int(accumulate), _p(ws), ws.numel(), _stream())
+              0, 0, int(accumulate), _p(ws), ws.numel(), rdy, _stream())
         return dx
     wt = conv2d_wt(w, out=workspace(4 * w.numel(), dy.device, "wt")[: 4 * w.numel()].view(torch.float32)
                    .view(Cin, Cout * KH * KW))
@@ -301,14 +394,14 @@ def bn_bwd_pre(dy, x, relu, scale, shift, save_mean, save_invstd, gamma, dgamma=
     return coef3, dgamma, dbeta
 
 
-def conv1x1_dgrad_bnb(g, z, coef3, w, x_shape, out=None, accumulate=False):
+def conv1x1_dgrad_bnb(g, z, coef3, w, x_shape, out=None, accumulate=False, wp=None):
     _chk(g, z, coef3, w, out)
     B, Cin, H, W = x_shape
     Cout = w.shape[0]
     dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=g.device)
-    ws = workspace(lib().scat_conv1x1_s1_ws(Cin, Cout), g.device, "wt")
+    ws, rdy = _wp_ws(wp, w, WPREP_CONV1X1_DGRAD, Cout, Cin, 1, 1, 0, lib().scat_conv1x1_s1_ws(Cin, Cout), g.device)
     _prof(2.0 * B * H * W * Cout * Cin, lib().scat_conv1x1_s1_bnb, _p(g), _p(z), _p(coef3), _p(w), _p(dx), B, Cin, H * W,
-          Cout, int(accumulate), _p(ws), ws.numel(), _stream())
+          Cout, int(accumulate), _p(ws), ws.numel(), rdy, _stream())
     return dx
 
 

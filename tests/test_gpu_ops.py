@@ -271,6 +271,59 @@ def test_wgrad_stride2_split(ops, B, cin, cout, H, W, k):
         assert rel_err(got, ref) < 2e-5, tf
 
 
+def test_prepared_weights(ops):
+    """ops.WeightPrep (scat_wprep_jobs / scat_wprep_run): after one registering pass, a single batched launch re-lays
+    the weights of every (convolution, direction) and the entry points run with w_ready = 1 — results must be
+    BIT-identical to the self-preparing calls, for all six kinds, and must follow an in-place weight update."""
+    assert ops.get_math_mode() == 1
+    B = 2
+    cases = [  # cin, cout, k, stride, H
+        (32, 48, 1, 1, 9), (48, 32, 3, 1, 10), (32, 64, 3, 2, 11), (64, 32, 1, 2, 12), (16, 80, 3, 2, 8)]
+    ws, xs, dys = [], [], []
+    for n, (cin, cout, k, s, H) in enumerate(cases):
+        ws.append(g(t(300 + n, "w", (cout, cin, k, k), std=0.1)))
+        xs.append(g(t(310 + n, "x", (B, cin, H, H))))
+        OH, _ = ops.conv_out_hw(H, H, k, s, k // 2)
+        dys.append(g(t(320 + n, "dy", (B, cout, OH, OH))))
+
+    def run_all(wp):
+        outs = []
+        for (cin, cout, k, s, H), w, x, dy in zip(cases, ws, xs, dys):
+            outs.append(ops.conv2d_fwd(x, w, s, k // 2, wp=wp))
+            outs.append(ops.conv2d_dgrad_w(dy, w, tuple(x.shape), s, k // 2, wp=wp))
+        return outs
+
+    ref = run_all(None)
+    wp = ops.WeightPrep()
+    wp.run(False)                                   # nothing registered yet: no-op
+    first = run_all(wp)                             # registers; every call still prepares for itself
+    assert len(wp.entries) == 2 * len(cases) and not any(e[2] for e in wp.entries.values())
+    wp.run(False)                                   # builds the table, one launch
+    assert wp.table is not None and all(e[2] for e in wp.entries.values())
+    kinds = sorted({k for _, k in wp.entries})
+    assert kinds == [0, 1, 2, 3, 4, 5], kinds
+    for e in wp.entries.values():                   # poison check: run() must have rewritten every workspace
+        assert e[2]
+    second = run_all(wp)                            # w_ready = 1 everywhere
+    for a, b, c in zip(ref, first, second):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    # stale detection in inference mode: an in-place update bumps the version counter -> run() re-lays
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5)
+    wp.run(False)
+    third = run_all(wp)
+    ref2 = run_all(None)
+    for a, b in zip(ref2, third):
+        assert torch.equal(a, b)
+    assert not torch.equal(ref[0], ref2[0])
+    # a training-mode run marks the cache dirty (the optimiser's update is invisible): next inference run re-lays
+    wp.run(True)
+    assert wp.dirty
+    wp.run(False)
+    assert not wp.dirty
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 8, 8), (3, 5, 7, 9), (1, 2, 14, 14), (2, 4, 5, 12), (1, 1, 1, 1)])
 def test_subsample2(ops, shape):
     """x[:, :, ::2, ::2] packed: even/odd planes, vector and scalar paths; bit-exact (a copy)."""
