@@ -281,15 +281,20 @@ class _BackboneFn(torch.autograd.Function):
                     put(dsw, wgrad(dcd, sd.xs, dsw, 1, 0))
                 else:
                     put(dsw, wgrad(dcd, xin, dsw, blk.stride, 0))
-                dxin = ops.conv2d_dgrad_w(dcd, dsw, tuple(xin.shape), blk.stride, 0, wp=wp)
-                del dcd
+                dxin = None     # conv1's data gradient is written first, the shortcut's lands on top of it: at
+                                # stride 2 that touches only the even pixels (no zero fill, no read-modify-write
+                                # of the whole plane)
             else:
                 dxin = g
             if fold1:
-                dcur = ops.conv1x1_dgrad_bnb(da1, c1, coef1, w1, tuple(xin.shape), out=dxin, accumulate=True, wp=wp)
+                dcur = ops.conv1x1_dgrad_bnb(da1, c1, coef1, w1, tuple(xin.shape), out=dxin, accumulate=dxin is not None,
+                                             wp=wp)
             else:
-                dcur = ops.conv2d_dgrad_w(dc1, w1, tuple(xin.shape), 1, 0, out=dxin, accumulate=True, wp=wp)
+                dcur = ops.conv2d_dgrad_w(dc1, w1, tuple(xin.shape), 1, 0, out=dxin, accumulate=dxin is not None, wp=wp)
                 del dc1
+            if cd is not None:
+                dcur = ops.conv2d_dgrad_w(dcd, dsw, tuple(xin.shape), blk.stride, 0, out=dcur, accumulate=True, wp=wp)
+                del dcd
             del da1, g
             remaining -= 1
             if remaining == 0:
