@@ -38,6 +38,66 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     }
 }
 
+// even H, W % 4 == 0 (the stem: 112x112 -> 56x56): a thread owns the output pair (oy, 2q), (oy, 2q+1) and reads, per
+// window row, the aligned float4 of columns 4q..4q+3 plus column 4q-1 (the neighbouring lane's .w when that lane holds
+// the previous quad of the same row).  Same scan order and tie/NaN rule as the scalar kernel: bit-identical results.
+__global__ __launch_bounds__(256) void maxpool_fwd_pair_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int relu,
+                                                               float* __restrict__ y, int8_t* __restrict__ idx,
+                                                               int64_t total, int C, int H, int W, int OH, int OW) {
+    const int QW = OW / 2;                                // pairs per output row
+    const int lane = threadIdx.x & 63;
+    const int64_t e0 = blockIdx.x * 256ll + threadIdx.x;
+    const int64_t stride = gridDim.x * 256ll;
+    // every lane of a wavefront runs the same number of iterations (the shuffle below needs its neighbour alive)
+    const int64_t wave0 = e0 - lane;
+    for (int64_t base = wave0; base < total; base += stride) {
+        const int64_t e = base + lane;
+        const bool live = e < total;
+        const int64_t ee = live ? e : 0;
+        const int q = (int)(ee % QW);
+        const int64_t r = ee / QW;
+        const int oy = (int)(r % OH);
+        const int64_t nc = r / OH;
+        const int c = (int)(nc % C);
+        const float* p = x + nc * H * W;
+        const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+        float best0 = -INFINITY, best1 = -INFINITY;
+        int b0 = -1, b1 = -1;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = oy * 2 - 1 + kh;
+            const bool rowok = (unsigned)iy < (unsigned)H;          // (uniform per output row, not per wavefront)
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rowok) v = *reinterpret_cast<const float4*>(p + iy * W + 4 * q);
+            // column 4q-1: the previous lane's .w when it holds quad q-1 of the same (plane, row)
+            float left = __shfl_up(v.w, 1);
+            if (q > 0 && lane == 0 && rowok) left = p[iy * W + 4 * q - 1];
+            if (!rowok) continue;
+            float t[5] = {left, v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (scale) t[j] = fmaf(t[j], sc, sh);
+                if (relu) t[j] = fmaxf(t[j], 0.f);
+            }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                if (!(kw == 0 && q == 0)) {                       // column -1 is padding
+                    const float a = t[kw];
+                    if (a > best0 || a != a) { best0 = a; b0 = kh * 3 + kw; }
+                }
+                const float b = t[2 + kw];
+                if (b > best1 || b != b) { best1 = b; b1 = kh * 3 + kw; }
+            }
+        }
+        if (live) {
+            *reinterpret_cast<float2*>(y + 2 * e) = make_float2(best0, best1);
+            *reinterpret_cast<char2*>(idx + 2 * e) = make_char2((signed char)b0, (signed char)b1);
+        }
+    }
+}
+
 // gather form (no atomics): an input pixel sums the windows whose arg-max it is.
 // generic sizes: grid.y = (n,c) plane, threads sweep the plane.
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
@@ -171,6 +231,12 @@ extern "C" int scat_maxpool3x3s2_fwd(const float* x, const float* scale, const f
     SCAT_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, SCAT_E_SHAPE, "scat_maxpool3x3s2_fwd: non-positive dimension");
     int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     int64_t total = (int64_t)B * C * OH * OW;
+    if (H % 2 == 0 && W % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 && ((uintptr_t)idx & 1) == 0) {
+        hipLaunchKernelGGL(maxpool_fwd_pair_kernel, dim3(grid_for(total / 2)), dim3(256), 0, (hipStream_t)stream, x,
+                           scale, shift, relu, y, idx, total / 2, C, H, W, OH, OW);
+        SCAT_LAUNCH_CHECK("scat_maxpool3x3s2_fwd");
+        return SCAT_OK;
+    }
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
                        relu, y, idx, total, C, H, W, OH, OW);
     SCAT_LAUNCH_CHECK("scat_maxpool3x3s2_fwd");

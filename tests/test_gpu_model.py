@@ -416,3 +416,43 @@ def test_encoder_performer_config5():
         if p.requires_grad:
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
     assert net.blocks[0].w.grad is None                                      # frozen random features
+
+
+def test_prepared_weights_follow_training():
+    """The backbone's prepared weights (ops.WeightPrep: one re-layout launch per step) must never go stale: two train
+    steps (the optimiser's update is a raw kernel, invisible to autograd's version counters) and an inference forward
+    in between / after give exactly the outputs of the same sequence with every convolution re-laying its own weights
+    (ops.WPREP = False)."""
+    from scat_amd import ops
+    from scat_amd.trainer import TrainStep
+
+    def sequence(use_prep):
+        saved = ops.WPREP
+        ops.WPREP = use_prep
+        try:
+            net = make_encoder(77)
+            net.train()
+            ts = TrainStep(net, lr=1e-3)
+            outs = []
+            xe = T(synth.images(171, 2)).cuda()
+            for step in range(3):
+                x, lab = T(synth.images(172 + step, 4)).cuda(), T(synth.labels(182 + step, 4)).cuda()
+                random.seed(5 + step)
+                loss, _, _, pred = ts(x, lab)
+                outs.append(pred.detach().cpu())
+                net.eval()
+                with torch.no_grad():
+                    for _ in range(2):            # second call: nothing changed, nothing is re-laid
+                        random.seed(50 + step)
+                        outs.append(net(xe)[0].cpu())
+                net.train()
+            if use_prep:
+                wp = net.main_encoder._wprep
+                assert len(wp.entries) > 100 and wp.table is not None and all(e[2] for e in wp.entries.values())
+            return outs
+        finally:
+            ops.WPREP = saved
+
+    a, b = sequence(True), sequence(False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

@@ -461,6 +461,19 @@ def test_pools(ops):
     # ties at exactly 0 after ReLU are killed by the ReLU mask downstream: compare on a>0
     m = (a > 0).double()
     assert rel_err(da.cpu().double() * m, a.grad.double() * m) < 1e-6
+    # pair kernel (even H, W % 4 == 0): values bit-exact and arg-max taps equal to ATen's, rows shorter and longer than
+    # a wavefront (left neighbour from the previous lane / from memory / padding)
+    for n, shp in enumerate([(2, 3, 6, 8), (1, 2, 4, 260), (2, 2, 10, 132)]):
+        xp = t(200 + n, "xp", shp)
+        yt, it = F.max_pool2d(xp, 3, 2, 1, return_indices=True)
+        yp, ip = ops.maxpool_fwd(g(xp))
+        assert torch.equal(yp.cpu(), yt)
+        OH, OW = yt.shape[2:]
+        oy = torch.arange(OH).view(1, 1, OH, 1)
+        ox = torch.arange(OW).view(1, 1, 1, OW)
+        tap = ip.cpu().long()
+        flat = (2 * oy - 1 + tap // 3) * shp[3] + (2 * ox - 1 + tap % 3)
+        assert torch.equal(flat, it)
     # odd size, no fused transform
     x2 = t(28, "x2", (2, 5, 13, 13))
     y2g, _ = ops.maxpool_fwd(g(x2))
