@@ -105,14 +105,27 @@ __global__ void tokens_bwd_kernel(const float* __restrict__ dy, const int32_t* _
         dx[e] = m ? 0.f : dy[e];
     }
 }
-__global__ void tokens_dmask_kernel(const float* __restrict__ dy, const int32_t* __restrict__ masked, int nmasked,
-                                    float* __restrict__ dmask, int B, int T, int D) {
-    int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
+// d(mask_token)[d] = sum over images and masked rows of dy.  A workgroup owns 64 consecutive d; its 16 wavefronts
+// take the images b = w, w + 16, ... and their partial sums are combined in wavefront order (fixed order, and
+// B x nmasked loads per thread become B/16 x nmasked).
+__global__ __launch_bounds__(1024) void tokens_dmask_kernel(const float* __restrict__ dy,
+                                                            const int32_t* __restrict__ masked, int nmasked,
+                                                            float* __restrict__ dmask, int B, int T, int D) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int b = 0; b < B; ++b)
-        for (int k = 0; k < nmasked; ++k) s += dy[((int64_t)b * T + masked[k]) * D + d];
-    dmask[d] = s;
+    if (d < D)
+        for (int b = wave; b < B; b += 16)
+            for (int k = 0; k < nmasked; ++k) s += dy[((int64_t)b * T + masked[k]) * D + d];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && d < D) {
+        float t = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) t += part[w][lane];
+        dmask[d] = t;
+    }
 }
 
 // ---------------------------------------------------------------- regressor head
@@ -126,15 +139,36 @@ __global__ __launch_bounds__(256) void regressor_fwd_kernel(const float* __restr
                                                             float* __restrict__ out, int B, int F, int P, int iters,
                                                             int root_rel) {
     __shared__ float base[128], pred[128], upd[128];
+    __shared__ float fsh[2048];                        // this sample's feature row (F <= 2048), read by every output
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ldw = F + P;
     const float* fb = feat + (int64_t)b * F;
-    for (int j = wave; j < P; j += 4) {
-        float s = 0.f;
-        for (int f = lane; f < F; f += 64) s = fmaf(w[(int64_t)j * ldw + f], fb[f], s);
+    const bool staged = F <= 2048;
+    if (staged) {
+        for (int f = tid; f < F; f += 256) fsh[f] = fb[f];
+        __syncthreads();
+    }
+    // two outputs per pass: twice the weight loads in flight per wavefront (the loop is latency-bound)
+    for (int j = wave; j < P; j += 8) {
+        const int j2 = j + 4;
+        const bool has2 = j2 < P;
+        const float* w0 = w + (int64_t)j * ldw;
+        const float* w1 = w + (int64_t)(has2 ? j2 : j) * ldw;
+        float s0 = 0.f, s1 = 0.f;
+        for (int f = lane; f < F; f += 64) {
+            const float x = staged ? fsh[f] : fb[f];
+            s0 = fmaf(w0[f], x, s0);
+            s1 = fmaf(w1[f], x, s1);
+        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) base[j] = s + bias[j];
+        for (int o = 32; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o, 64);
+            s1 += __shfl_xor(s1, o, 64);
+        }
+        if (lane == 0) {
+            base[j] = s0 + bias[j];
+            if (has2) base[j2] = s1 + bias[j2];
+        }
     }
     if (tid < P) {
         float v = mean[tid];
@@ -508,7 +542,7 @@ extern "C" int scat_tokens_bwd(const float* dy, const int32_t* masked, int nmask
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(tokens_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, dy, masked, nmasked, dx, n, T, D);
     if (dmask_token)
-        hipLaunchKernelGGL(tokens_dmask_kernel, dim3(cdiv(D, 128)), dim3(128), 0, st, dy, masked, nmasked, dmask_token,
+        hipLaunchKernelGGL(tokens_dmask_kernel, dim3(cdiv(D, 64)), dim3(1024), 0, st, dy, masked, nmasked, dmask_token,
                            B, T, D);
     SCAT_LAUNCH_CHECK("scat_tokens_bwd");
     return SCAT_OK;
@@ -543,8 +577,18 @@ extern "C" int scat_regressor_bwd(const float* dout, const float* feat, const fl
     hipLaunchKernelGGL(regressor_bwd_delta_kernel, dim3(B), dim3(128), 0, st, dout, w, deltas, dsum, dfeat_out, B, F,
                        P, iters, root_relative);
     int64_t nw = (int64_t)P * (F + P);
-    hipLaunchKernelGGL(regressor_bwd_w_kernel, dim3((int)((nw + 255) / 256)), dim3(256), 0, st, feat, preds,
-                       (const float*)deltas, (const float*)dsum, dw, dbias, B, F, P, iters);
+    if (iters > 0) {
+        // dW = [dsum^T . feat | sum_t deltas_t^T . preds_t], dbias = column sums of dsum: three small contractions on
+        // the general engine instead of a 96..288-long dependent FMA chain per element
+        const int ldw = F + P;
+        if (int e = scat_gemm(dsum, 1, P, feat, F, 1, dw, ldw, 1, P, F, B, nullptr, 0, 0, nullptr, 0, stream)) return e;
+        if (int e = scat_gemm(deltas, 1, P, preds, P, 1, dw + F, ldw, 1, P, P, iters * B, nullptr, 0, 0, nullptr, 0, stream))
+            return e;
+        if (int e = scat_colsum(dsum, dbias, B, P, 0, stream)) return e;
+    } else {
+        hipLaunchKernelGGL(regressor_bwd_w_kernel, dim3((int)((nw + 255) / 256)), dim3(256), 0, st, feat, preds,
+                           (const float*)deltas, (const float*)dsum, dw, dbias, B, F, P, iters);
+    }
     int64_t nf = (int64_t)B * F;
     hipLaunchKernelGGL(regressor_bwd_feat_kernel, dim3((int)((nf + 255) / 256)), dim3(256), 0, st,
                        (const float*)dsum, w, dfeat, B, F, P);
