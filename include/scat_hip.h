@@ -132,10 +132,12 @@ int scat_bn_train_stats(const float* x, int B, int C, int HW, const float* gamma
 /* inference: scale/shift from running stats */
 int scat_bn_eval_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, int C, float* scale, float* shift, void* stream);
-/* y = [relu]( x*scale[c] + shift[c] [+ residual] ).  mask_out (optional, HW % 4 == 0): B*C*HW/4 bytes, bit q of
- * byte e = (y[4e+q] > 0) — all the backward needs of y, at 1/32 of its bytes. */
-int scat_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, int relu, float* y,
-                  uint8_t* mask_out, int B, int C, int HW, void* stream);
+/* y = [relu]( x*scale[c] + shift[c] [+ residual] ), or with res_scale/res_shift [+ residual*res_scale[c] +
+ * res_shift[c]]: the shortcut branch's BatchNorm (models/resnet.py:92-96) applied while adding, its output never
+ * materialised.  mask_out (optional, HW % 4 == 0): B*C*HW/4 bytes, bit q of byte e = (y[4e+q] > 0) — all the
+ * backward needs of y, at 1/32 of its bytes. */
+int scat_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, const float* res_scale,
+                  const float* res_shift, int relu, float* y, uint8_t* mask_out, int B, int C, int HW, void* stream);
 /* backward of y = [relu](bn(x) [+res]):  g = dy * (mask);  mask from y_out>0 (if y_out), from the sign mask of
  * scat_bn_apply (if y_mask), else from x*scale+shift>0 (if relu), else 1.  Produces dgamma, dbeta, dx and (if dres)
  * dres (+)= g. */

@@ -114,24 +114,32 @@ __global__ void bn_eval_fold_kernel(const float* gamma, const float* beta, const
 template <int V>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
-                                                       const float* __restrict__ res, int relu,
+                                                       const float* __restrict__ res,
+                                                       const float* __restrict__ rscale,
+                                                       const float* __restrict__ rshift, int relu,
                                                        float* __restrict__ y, uint8_t* __restrict__ mask,
                                                        int64_t nvec, FastDiv dHWv, FastDiv dC) {
     for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < nvec; e += gridDim.x * 256ll) {
         const uint32_t row = dHWv.div((uint32_t)e);
         const int c = (int)(row - dC.div(row) * dC.d);
         const float sc = scale[c], sh = shift[c];
+        // the residual may itself be a raw convolution output with its own BatchNorm (the shortcut branch)
+        const float rs = rscale ? rscale[c] : 1.f, rh = rscale ? rshift[c] : 0.f;
         if (V == 4) {
             float4 v = ((const float4*)x)[e];
             v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
-            if (res) { float4 r = ((const float4*)res)[e]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (res) {
+                float4 r = ((const float4*)res)[e];
+                if (rscale) { r.x = fmaf(r.x, rs, rh); r.y = fmaf(r.y, rs, rh); r.z = fmaf(r.z, rs, rh); r.w = fmaf(r.w, rs, rh); }
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             ((float4*)y)[e] = v;
             // sign bits of the output, one byte per float4: what the backward needs of y (32x fewer bytes)
             if (mask) mask[e] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
         } else {
             float v = fmaf(x[e], sc, sh);
-            if (res) v += res[e];
+            if (res) v += rscale ? fmaf(res[e], rs, rh) : res[e];
             if (relu) v = fmaxf(v, 0.f);
             y[e] = v;
         }
@@ -441,9 +449,12 @@ extern "C" int scat_bn_eval_fold(const float* gamma, const float* beta, const fl
     return SCAT_OK;
 }
 
-extern "C" int scat_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, int relu,
-                             float* y, uint8_t* mask_out, int B, int C, int HW, void* stream) {
+extern "C" int scat_bn_apply(const float* x, const float* scale, const float* shift, const float* residual,
+                             const float* res_scale, const float* res_shift, int relu, float* y, uint8_t* mask_out,
+                             int B, int C, int HW, void* stream) {
     SCAT_REQUIRE(x && scale && shift && y, SCAT_E_ARG, "scat_bn_apply: null pointer");
+    SCAT_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || residual), SCAT_E_ARG,
+                 "scat_bn_apply: residual scale/shift pair");
     SCAT_REQUIRE(B > 0 && C > 0 && HW > 0, SCAT_E_SHAPE, "scat_bn_apply: non-positive dimension");
     const int64_t total = (int64_t)B * C * HW;
     SCAT_REQUIRE(fits_i32(total), SCAT_E_SHAPE, "scat_bn_apply: tensor exceeds 2^31 elements");
@@ -451,12 +462,12 @@ extern "C" int scat_bn_apply(const float* x, const float* scale, const float* sh
     const bool vec = (HW & 3) == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
     if (vec) {
         const int64_t nv = total / 4;
-        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_grid(nv)), dim3(256), 0, st, x, scale, shift, residual, relu, y,
-                           mask_out, nv, FastDiv::make(HW / 4), FastDiv::make(C));
+        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_grid(nv)), dim3(256), 0, st, x, scale, shift, residual, res_scale,
+                           res_shift, relu, y, mask_out, nv, FastDiv::make(HW / 4), FastDiv::make(C));
     } else {
         SCAT_REQUIRE(!mask_out, SCAT_E_SHAPE, "scat_bn_apply: the sign mask needs HW % 4 == 0 and 16-B aligned tensors");
-        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, x, scale, shift, residual, relu,
-                           y, nullptr, total, FastDiv::make(HW), FastDiv::make(C));
+        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, x, scale, shift, residual, res_scale,
+                           res_shift, relu, y, nullptr, total, FastDiv::make(HW), FastDiv::make(C));
     }
     SCAT_LAUNCH_CHECK("scat_bn_apply");
     return SCAT_OK;

@@ -120,14 +120,15 @@ class _BackboneFn(torch.autograd.Function):
                         cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0, wp=wp)
                     sd = _BNState(cd, blk.downsample[1], training)
                     sd.xs = xs if training else None
-                    res = ops.bn_apply(cd, sd.scale, sd.shift, None, False)
+                    res, rsc, rsh = cd, sd.scale, sd.shift      # the shortcut's BatchNorm is applied while adding
                 else:
                     cd = sd = None
-                    res = xin
+                    res, rsc, rsh = xin, None, None
                 if training:    # the backward wants only the sign of the block output: keep 1 bit per element for it
-                    cur, omask = ops.bn_apply(c3, s3.scale, s3.shift, res, True, want_mask=True)
+                    cur, omask = ops.bn_apply(c3, s3.scale, s3.shift, res, True, want_mask=True, res_scale=rsc,
+                                              res_shift=rsh)
                 else:
-                    cur, omask = ops.bn_apply(c3, s3.scale, s3.shift, res, True), None
+                    cur, omask = ops.bn_apply(c3, s3.scale, s3.shift, res, True, res_scale=rsc, res_shift=rsh), None
                 tape.append((blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, cur, omask))
             feats.append(cur)
         if _NBT:

@@ -347,16 +347,17 @@ def bn_eval_fold(gamma, beta, running_mean, running_var, eps=1e-5):
     return o[0], o[1]
 
 
-def bn_apply(x, scale, shift, residual=None, relu=False, out=None, want_mask=False):
+def bn_apply(x, scale, shift, residual=None, relu=False, out=None, want_mask=False, res_scale=None, res_shift=None):
     """want_mask: also return the sign mask of the output (uint8, one byte per 4 elements; None when the plane is not
     a multiple of 4) — what bn_bwd needs of y, 32x smaller."""
-    _chk(x, scale, shift, residual, out)
+    _chk(x, scale, shift, residual, out, res_scale, res_shift)
     B, C, H, W = x.shape
     y = out if out is not None else torch.empty_like(x)
     mask = None
     if want_mask and (H * W) % 4 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in (x, y, residual)):
         mask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=x.device)
-    lib().scat_bn_apply(_p(x), _p(scale), _p(shift), _p(residual), int(relu), _p(y), _p(mask), B, C, H * W, _stream())
+    lib().scat_bn_apply(_p(x), _p(scale), _p(shift), _p(residual), _p(res_scale), _p(res_shift), int(relu), _p(y),
+                        _p(mask), B, C, H * W, _stream())
     return (y, mask) if want_mask else y
 
 

@@ -445,6 +445,22 @@ def test_batchnorm_backward_folded_into_conv(ops, B, cin, cout, H):
     assert rel_err(daa, da_ref + base) < 2e-5
 
 
+def test_bn_apply_shortcut(ops):
+    """block output with the shortcut's BatchNorm folded into the add: relu(bn3(c3) + bnd(cd)), vector and scalar
+    paths, against the two-pass form (bit-exact: same operations in the same order)."""
+    for n, shp in enumerate([(2, 24, 6, 6), (3, 8, 5, 3)]):
+        c3, cd = g(t(400 + n, "c3", shp)), g(t(410 + n, "cd", shp))
+        C = shp[1]
+        s3, h3 = g(torch.from_numpy(synth.uniform(420, "s", (C,), 0.5, 1.5))), g(t(421, "h", (C,)))
+        sd, hd = g(torch.from_numpy(synth.uniform(422, "s", (C,), 0.5, 1.5))), g(t(423, "h", (C,)))
+        res = ops.bn_apply(cd, sd, hd, None, False)
+        two = ops.bn_apply(c3, s3, h3, res, True)
+        one = ops.bn_apply(c3, s3, h3, cd, True, res_scale=sd, res_shift=hd)
+        assert torch.equal(one, two)
+        ref = F.relu(c3 * s3.view(1, -1, 1, 1) + h3.view(1, -1, 1, 1) + cd * sd.view(1, -1, 1, 1) + hd.view(1, -1, 1, 1))
+        assert rel_err(one, ref) < 1e-6
+
+
 def test_pools(ops):
     B, C, H = 3, 16, 112
     x = t(24, "x", (B, C, H, H)).requires_grad_(True)
