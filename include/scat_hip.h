@@ -121,6 +121,16 @@ int scat_gemm(const float* a, int64_t a_si, int64_t a_sk, const float* b, int64_
               int64_t c_si, int64_t c_sj, int M, int N, int K, const float* bias, int bias_mode, int accumulate,
               void* ws, int64_t ws_bytes, void* stream);
 
+/* The same contraction on split-operand products (scat_get_math_mode() == 1), for the dense projections of the ViT
+ * blocks (models/vision_transformer.py:52,57,76: to_qkv, to_out and their gradients; FeedForward :33-35):
+ * c[M,N] (+)= op(a)[M,K] . b[K,N] (+ bias_n[N]); b and c row-major; a is [M,K] row-major, or stored [K,M] when
+ * a_transposed.  ws: scat_gemm_split_ws(M, K) bytes.  scat_transpose2d: dst[C,R] = src[R,C] (the W^T a forward
+ * projection needs as its b operand). */
+int64_t scat_gemm_split_ws(int M, int K);
+int scat_gemm_split(const float* a, int a_transposed, const float* b, float* c, int M, int N, int K, const float* bias_n,
+                    int accumulate, void* ws, int64_t ws_bytes, void* stream);
+int scat_transpose2d(const float* src, float* dst, int R, int C, void* stream);
+
 /* ---- BatchNorm2d, training + inference: models/resnet.py:68-73,108,131 (eps 1e-5, momentum .1) ----
  * stats: per-channel batch mean / biased variance (fp64 accumulation, fixed reduction order), folded
  * into scale = gamma*invstd, shift = beta - mean*scale; running stats updated (unbiased var).

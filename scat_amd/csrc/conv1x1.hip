@@ -738,3 +738,78 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
     SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
     return SCAT_OK;
 }
+
+// ---------------------------------------------------------------- dense GEMM on the pointwise split kernel
+//
+// C[M][N] (+)= op(A)[M][K] . B[K][N] (+ bias[N]); B and C row-major, A either [M][K] (a_transposed = 0) or stored
+// [K][M] (a_transposed = 1).  This IS the pointwise convolution above with one image: A plays the weights (split once
+// into MFMA operand planes by the re-layout launch: ws), B the activations [K channels][N pixels] that are split on
+// their way into LDS, C the NCHW output [1][M][N].  It puts the ViT projections (vision_transformer.py:46-79:
+// x.Wqkv^T, attn.Wout^T and their gradients, M = 2016 tokens at batch 96) on split-operand products:
+//   forward   y  = x . W^T      A = x [M][K],             B = W^T [K][N] (scat_transpose2d of the weight)
+//   dgrad     dx = dy . W       A = dy [M][N'],           B = W [N'][K'] as stored
+//   wgrad     dW = dy^T . x     A = dy, a_transposed = 1, B = x [tokens][K] as stored
+// K need not be a multiple of 16 (the re-layout pads A, the activation loads mask the ragged channels).
+extern "C" int64_t scat_gemm_split_ws(int M, int K) { return taps_split_ws(M, K, 1); }
+
+extern "C" int scat_gemm_split(const float* a, int a_transposed, const float* b, float* c, int M, int N, int K,
+                               const float* bias_n, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+    SCAT_REQUIRE(a && b && c, SCAT_E_ARG, "scat_gemm_split: null pointer");
+    SCAT_REQUIRE(M > 0 && N > 0 && K > 0, SCAT_E_SHAPE, "scat_gemm_split: non-positive dimension");
+    SCAT_REQUIRE(math_mode() == 1, SCAT_E_ARG, "scat_gemm_split: needs the split-operand product mode");
+    SCAT_REQUIRE(ws && ws_bytes >= scat_gemm_split_ws(M, K) && ((uintptr_t)ws & 15) == 0, SCAT_E_WORKSPACE,
+                 "scat_gemm_split: workspace too small / unaligned");
+    SCAT_REQUIRE(fits_i32((int64_t)K * N * 4) && fits_i32((int64_t)M * N * 4) && fits_i32((int64_t)M * K * 4),
+                 SCAT_E_SHAPE, "scat_gemm_split: operand exceeds 32-bit byte offsets");
+    hipStream_t st = (hipStream_t)stream;
+    wprep_launch(wprep_job(a, ws, M, K, a_transposed, 1, 1, 1, 1, 0, 0, 1), st);
+    PwDesc d{};
+    d.src = b; d.C = K; d.M = M; d.HW = N; d.npix = N; d.dHW = FastDiv::make(N);
+    d.ntap = 1; d.KWt = 1; d.a = 1; d.tb = 1; d.c0y = 0; d.c0x = 0; d.H = 1; d.W = N; d.OW = N; d.OHW = N;
+    d.dOHW = FastDiv::make(N); d.dOW = FastDiv::make(N);
+    d.nsrc = (int64_t)K * N; d.variant = tuning();
+    const int64_t nel = (int64_t)M * ((K + 15) / 16 * 16);
+    d.w = (const float*)ws;
+    d.nw = (nel * 6 + 3) / 4;
+    OutDesc dc{};
+    dc.p = c; dc.mode = 1; dc.I = M; dc.J = N; dc.C = M; dc.HW = N; dc.dHW = FastDiv::make(N);
+    dc.bias = bias_n; dc.bias_mode = bias_n ? 2 : 0; dc.accumulate = accumulate; dc.n = (int64_t)M * N;
+    // few, small problems (2016 x 1536 x 784 is the largest): the tile is chosen for workgroup count first
+    auto tiles = [&](int bm, int bn) { return (int64_t)cdiv(M, bm) * cdiv(N, bn); };
+    int cfg = tiles(128, 128) >= 512 ? 0 : (tiles(64, 128) >= 512 ? 1 : 2);
+    if (tuning() >= 1 && tuning() <= 3) cfg = tuning() - 1;
+    static const char* const names[] = {"128x128", "64x128", "64x64"};
+    set_kernel_label("gemm_split_%sx32", names[cfg]);
+    if (cfg == 0) launch_pw_split<4, 128, false>(d, dc, st);
+    else if (cfg == 1) launch_pw_split<2, 128, false>(d, dc, st);
+    else launch_pw_split<2, 64, false>(d, dc, st);
+    SCAT_LAUNCH_CHECK("scat_gemm_split");
+    return SCAT_OK;
+}
+
+// dst[C][R] = src[R][C] (row-major): the weight transpose of the forward projection above
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int R,
+                                                          int C) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, cc = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < R && cc < C) ? src[(int64_t)r * C + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cc = c0 + ty + 8 * k, r = r0 + tx;
+        if (cc < C && r < R) dst[(int64_t)cc * R + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+extern "C" int scat_transpose2d(const float* src, float* dst, int R, int C, void* stream) {
+    SCAT_REQUIRE(src && dst && R > 0 && C > 0, SCAT_E_ARG, "scat_transpose2d: bad argument");
+    hipLaunchKernelGGL(transpose2d_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       R, C);
+    SCAT_LAUNCH_CHECK("scat_transpose2d");
+    return SCAT_OK;
+}

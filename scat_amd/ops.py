@@ -290,12 +290,36 @@ def gemm(a, a_si, a_sk, b, b_sk, b_sj, c, c_si, c_sj, M, N, K, bias=None, bias_m
     return c
 
 
+GEMM_SPLIT = os.environ.get("SCAT_GEMM_SPLIT", "1") != "0"        # dense projections on split-operand products
+# M*N*K below which the fp32 engine stays: measured (tools/vit_gemm_bench.py, M = 2016 tokens) the split kernel wins only
+# on the largest projection (qkv of layer 0, 2016 x 1536 x 784: 59 vs 72 us); the smaller ones are occupancy-bound
+# (49..768 workgroups on 256 CUs) and lose to the fp32 engine's split-K + 16-channel stages
+GEMM_SPLIT_MIN = int(os.environ.get("SCAT_GEMM_SPLIT_MIN", str(1 << 31)))
+
+
+def _gemm_split_ok(M, N, K):
+    return (GEMM_SPLIT and lib().scat_get_math_mode() == 1 and M >= 128 and N >= 64 and K >= 64
+            and M * N * K >= GEMM_SPLIT_MIN)
+
+
+def gemm_split(a, a_transposed, b, c, M, N, K, bias_n=None, accumulate=False):
+    """c[M,N] (+)= op(a)[M,K] @ b[K,N] (+ bias_n) on the pointwise split kernel (scat_gemm_split)"""
+    ws = workspace(lib().scat_gemm_split_ws(M, K), c.device, "gs")
+    _prof(2.0 * M * N * K, lib().scat_gemm_split, _p(a), int(a_transposed), _p(b), _p(c), M, N, K, _p(bias_n),
+          int(accumulate), _p(ws), ws.numel(), _stream())
+    return c
+
+
 def linear_fwd(x2d, w, bias=None, out=None, accumulate=False):
     """y[M,N] (+)= x[M,K] @ w[N,K]^T + bias"""
     _chk(x2d, w, bias, out)
     M, K = x2d.shape
     N = w.shape[0]
     y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=x2d.device)
+    if _gemm_split_ok(M, N, K):
+        wt = workspace(4 * K * N, w.device, "wT")[: 4 * K * N].view(torch.float32)
+        lib().scat_transpose2d(_p(w), _p(wt), N, K, _stream())
+        return gemm_split(x2d, 0, wt, y, M, N, K, bias, accumulate)
     return gemm(x2d, K, 1, w, 1, K, y, N, 1, M, N, K, bias, 2 if bias is not None else 0, accumulate)
 
 
@@ -305,6 +329,8 @@ def linear_dgrad(dy2d, w, out=None, accumulate=False):
     M, N = dy2d.shape
     K = w.shape[1]
     dx = out if out is not None else torch.empty((M, K), dtype=torch.float32, device=dy2d.device)
+    if _gemm_split_ok(M, K, N):
+        return gemm_split(dy2d, 0, w, dx, M, K, N, None, accumulate)
     return gemm(dy2d, N, 1, w, K, 1, dx, K, 1, M, K, N, accumulate=accumulate)
 
 
@@ -314,6 +340,8 @@ def linear_wgrad(dy2d, x2d, out=None):
     M, N = dy2d.shape
     K = x2d.shape[1]
     dw = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=x2d.device)
+    if _gemm_split_ok(N, K, M):
+        return gemm_split(dy2d, 1, x2d, dw, N, K, M)
     return gemm(dy2d, 1, N, x2d, K, 1, dw, K, 1, N, K, M)
 
 

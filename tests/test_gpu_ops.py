@@ -343,6 +343,8 @@ def test_conv_bias_and_edge_batches(ops):
 @pytest.mark.parametrize("M,N,K", [(2016, 1536, 784), (2016, 784, 512), (84, 588, 784), (84, 3, 147),
                                    (96, 1024, 2048), (2016, 196, 294), (7, 66, 1090), (300, 200, 100)])
 def test_linear(ops, M, N, K):
+    """(the largest shape, 2016 x 1536 x 784, runs on scat_gemm_split in the default product mode, the others on the
+    fp32 engine: ops.GEMM_SPLIT_MIN)"""
     x = t(13, "x", (M, K)).requires_grad_(True)
     w = t(14, "w", (N, K), std=K ** -0.5).requires_grad_(True)
     b = t(15, "b", (N,))
@@ -353,6 +355,25 @@ def test_linear(ops, M, N, K):
     assert rel_err(ops.linear_dgrad(g(dy), g(w.detach())), dx_ref) < 2e-5
     assert rel_err(ops.linear_wgrad(g(dy), g(x.detach())), dw_ref) < 2e-5
     assert rel_err(ops.colsum(g(dy)), dy.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(2016, 1536, 392), (2016, 196, 512), (2016, 294, 392), (300, 200, 147),
+                                   (130, 70, 66), (2016, 1536, 196)])
+def test_gemm_split(ops, M, N, K):
+    """scat_gemm_split directly: contraction lengths that are not multiples of 16 or 32 (392, 196, 147, 66), ragged row
+    and column tiles, transposed A, bias and accumulate — the ViT projection shapes of layers 1 and 2."""
+    assert ops.get_math_mode() == 1
+    a = t(600, "a", (M, K))
+    b = t(601, "b", (K, N), std=K ** -0.5)
+    bias = t(602, "bias", (N,))
+    ref = a.double() @ b.double()
+    c = ops.gemm_split(g(a), 0, g(b), torch.empty(M, N, device="cuda"), M, N, K, g(bias))
+    assert "gemm_split" in ops.lib().scat_last_kernel().decode()
+    assert rel_err(c, ref + bias.double()) < 2e-5
+    at = g(a.t().contiguous())                                   # stored [K][M]
+    base = g(t(603, "base", (M, N)))
+    c2 = ops.gemm_split(at, 1, g(b), base.clone(), M, N, K, None, accumulate=True)
+    assert rel_err(c2, ref + base.double().cpu()) < 2e-5
 
 
 @pytest.mark.parametrize("B,C,H", [(4, 64, 56), (3, 256, 14), (5, 2048, 7), (2, 64, 112)])

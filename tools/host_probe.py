@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--batch", type=int, default=96)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--sync-debug", action="store_true")
+    ap.add_argument("--hi", action="store_true", help="run the step on a high-priority stream (side streams stay normal)")
     a = ap.parse_args()
     from scat_amd.trainer import TrainStep
 
@@ -24,6 +25,9 @@ def main():
     net = bench.make_net(1, dev)
     ts = TrainStep(net, lr=5e-4)
     x, lab = bench.build_inputs(a.batch, 100, dev)
+    if a.hi:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     for _ in range(5):
         ts(x, lab)
     torch.cuda.synchronize()
