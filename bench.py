@@ -85,16 +85,17 @@ def instantiation_of(label):
     """kernel label (scat_last_kernel) -> the template instantiation it launches, as tools/traffic_json.py names it"""
     import re
     tf = "t" if label.endswith("_tf") or "_tf_" in label else "f"
+    ds = "t" if "_bnb" in label else "f"      # dual-source operand (folded BatchNorm backward)
     m = re.search(r"_split_(\d+)x(\d+)x32", label)
     if m:       # pointwise / taps kernel: WM = rows / 32
-        return f"conv1x1_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf}>"
+        return f"conv1x1_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf},{ds}>"
     m = re.match(r"conv3x3_split_(\d+)x(\d+)x16", label)
     if m:
         return f"conv3x3_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf}>"
     m = re.match(r"wgrad(1x1|3x3)(_s2)?_split_(\d+)x(\d+)x16", label)
     if m:
         return (f"wgrad_split_kernel<{9 if m.group(1) == '3x3' else 1},{int(m.group(3)) // 64},{int(m.group(4)) // 64},"
-                f"{tf},{'t' if m.group(2) else 'f'}>")
+                f"{tf},{'t' if m.group(2) else 'f'},{ds}>")
     return label
 
 

@@ -1,8 +1,12 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 kernel_stats.csv: short kernel names, per-step ms."""
 import csv, re, sys
-path, steps = sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+path = sys.argv[1]
 rows = list(csv.DictReader(open(path)))
+if len(sys.argv) > 2 and sys.argv[2] == "auto":      # one Adam launch per train step
+    steps = float(next(r["Calls"] for r in rows if "adam_kernel" in r["Name"]))
+else:
+    steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 def short(n):
     n = re.sub(r'\(.*$', '', n).replace('void ', '').replace('scat::', '')
     n = n.replace('GatherLoader', 'G').replace('MatLoader', 'M').replace('gemm_kernel', 'gemm').replace(' ', '')
