@@ -12,6 +12,8 @@ input gradient only — that is the reference's pose-length term
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -106,6 +108,27 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
     d = dy.contiguous().reshape(M, -1)
     grads: List[Optional[torch.Tensor]] = [None] * len(tape.params)
     pi = len(tape.params)
+    # The parameter gradients (weight-gradient contractions, bias column sums) are not read by anything in this
+    # backward: they run on the backbone's side stream next to the data-gradient chain, whose kernels (M = 2016
+    # tokens) are far too small to fill the GPU on their own.  Joined before the node returns.
+    main = side = None
+    if want_param_grads and d.is_cuda and os.environ.get("SCAT_SIDE_HEAD", "1") != "0":
+        from . import resnet as _rn
+
+        side = _rn._side_stream(d.device)
+        main = torch.cuda.current_stream()
+
+    def pgrad(fn, *inputs):
+        if side is None:
+            return fn()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = fn()
+        for t in inputs:
+            t.record_stream(side)
+        out.record_stream(main)
+        return out
+
     for cfg, rec in zip(reversed(tape.cfgs), reversed(tape.recs)):
         cur, h, mu1, rs1, qkv, attn, ao, x1, h2, mu2, rs2, u, a, a1, mup, rsp = rec
         npar = cfg.nparams()
@@ -121,12 +144,12 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
         # ---- MLP
         da = ops.linear_dgrad(d, w2)
         if want_param_grads:
-            grads[pi + kf + 2] = ops.linear_wgrad(d, a)
-            grads[pi + kf + 3] = ops.colsum(d)
+            grads[pi + kf + 2] = pgrad(lambda d=d, a=a: ops.linear_wgrad(d, a), d, a)
+            grads[pi + kf + 3] = pgrad(lambda d=d: ops.colsum(d), d)
         du = ops.gelu_bwd(da, u)
         if want_param_grads:
-            grads[pi + kf] = ops.linear_wgrad(du, h2)
-            grads[pi + kf + 1] = ops.colsum(du)
+            grads[pi + kf] = pgrad(lambda du=du, h2=h2: ops.linear_wgrad(du, h2), du, h2)
+            grads[pi + kf + 1] = pgrad(lambda du=du: ops.colsum(du), du)
         dh2 = ops.linear_dgrad(du, w0)
         if cfg.ff_ln:
             dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, p[kn], mu2, rs2)
@@ -144,13 +167,13 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
         else:
             da1 = dx1
         if want_param_grads:
-            grads[pi + k + 1] = ops.linear_wgrad(da1, ao.view(M, inner))
-            grads[pi + k + 2] = ops.colsum(da1)
+            grads[pi + k + 1] = pgrad(lambda da1=da1, ao=ao: ops.linear_wgrad(da1, ao.view(M, inner)), da1, ao)
+            grads[pi + k + 2] = pgrad(lambda da1=da1: ops.colsum(da1), da1)
         dao = ops.linear_dgrad(da1, wout)
         dqkv = ops.attention_bwd(dao.view(B, n, inner), qkv.view(B, n, 3 * inner), attn, cfg.heads, cfg.dim_head,
                                  cfg.scale).view(M, 3 * inner)
         if want_param_grads:
-            grads[pi + k] = ops.linear_wgrad(dqkv, h)
+            grads[pi + k] = pgrad(lambda dqkv=dqkv, h=h: ops.linear_wgrad(dqkv, h), dqkv, h)
         dh = ops.linear_dgrad(dqkv, wqkv)
         if cfg.ln1:
             dx, dg1, db1 = ops.layernorm_bwd(dh, cur, p[0], mu1, rs1)
@@ -159,6 +182,8 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
         else:
             dx = dh
         d = ops.axpy(dx, dx1, 1.0, out=dx)
+    if side is not None:
+        main.wait_stream(side)
     return d.view(B, n, -1), (grads if want_param_grads else None)
 
 
