@@ -107,12 +107,16 @@ def dominant_kernel_roofline(ts, x, lab):
 
     # per-kernel durations are only meaningful when kernels do not share the GPU: this one step runs the
     # weight gradients on the main stream instead of the side stream (the timed steps overlap them)
+    from scat_amd.models import hand_net as hand_net_mod
+
     side, resnet_mod.SIDE_WGRAD = resnet_mod.SIDE_WGRAD, False
+    overlap, hand_net_mod.OVERLAP_TOKENS = hand_net_mod.OVERLAP_TOKENS, False     # (and the token path in line)
     ops.PROFILE = []
     ts(x, lab)
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
     resnet_mod.SIDE_WGRAD = side
+    hand_net_mod.OVERLAP_TOKENS = overlap
     agg = {}
     for name, flops, e0, e1 in rec:
         ms = e0.elapsed_time(e1)

@@ -115,7 +115,7 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
     if want_param_grads and d.is_cuda and os.environ.get("SCAT_SIDE_HEAD", "1") != "0":
         from . import resnet as _rn
 
-        side = _rn._side_stream(d.device)
+        side = _rn._side_stream(d.device, "tokens")
         main = torch.cuda.current_stream()
 
     def pgrad(fn, *inputs):

@@ -13,6 +13,7 @@ constructor; ``pl_term`` carries no gradient.
 """
 from __future__ import annotations
 
+import os
 import random
 
 import numpy as np
@@ -58,6 +59,17 @@ def _upload_indices(idx, device):
     if torch.device(device).type != "cuda":
         return h.to(device)
     return h.pin_memory().to(device, non_blocking=True)
+
+
+OVERLAP_TOKENS = os.environ.get("SCAT_OVERLAP_TOKENS", "1") != "0"   # token path next to layer3/layer4 (own stream)
+_TOKEN_STREAMS = {}
+
+
+def _token_stream(device):
+    key = str(device)
+    if key not in _TOKEN_STREAMS:
+        _TOKEN_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _TOKEN_STREAMS[key]
 
 
 class _TokensFn(torch.autograd.Function):
@@ -249,9 +261,9 @@ class EncoderTransformer(nn.Module):
             self._midx_cache[key] = t
         return t
 
-    def forward(self, main_input):
-        auto_attach(self)   # WORLD_SIZE > 1: data-parallel gradient averaging without touching train.py
-        main_feat, x1, x2, x3, x4 = self.main_encoder(main_input)
+    def _token_path(self, x2):
+        """everything that depends on x2 only (hand_net.py:362-378, 395-396): 1x1 reduction, +PE, mask-token scatter,
+        the dim-halving transformer and, with pl_reg, the pose-length term"""
         feat_visual = self.conv1x1_channel_reduction(x2)                      # [B,21,28,28]
         B = feat_visual.size(0)
         midx = self._draw_mask(feat_visual.device)
@@ -259,13 +271,45 @@ class EncoderTransformer(nn.Module):
         tokens = _TokensFn.apply(feat_visual.view(B, 21, -1), pe, self.mask_token, midx)
         self.transformer._holder.want_tape = bool(self.pl)
         feat_out = self.transformer(tokens, None)                             # [B,21,3]
-        pred_params = _RegressorFn.apply(main_feat, feat_out.reshape(B, -1), self.mean_params.reshape(-1),
-                                         self.regressor.weight, self.regressor.bias, self.iteration)
+        pl_term = None
         if self.pl:
             # d sum(feat_out) / d feat_visual, no graph (hand_net.py:396): replay the mixer tape for the
             # input gradient only, then undo the token scatter.
             dtok = self.transformer.input_grad(torch.ones_like(feat_out))
             pl_term = ops.tokens_bwd(dtok.contiguous(), midx, want_dmask=False)[0].view_as(feat_visual)
+        return feat_visual, feat_out, pl_term
+
+    def _overlap_ok(self, x):
+        # (unattended data-parallel mode reduces the head bucket from parameter hooks on whatever stream they fire:
+        # it keeps the single-stream schedule)
+        sink = getattr(self.main_encoder, "_grad_sink", None)
+        return OVERLAP_TOKENS and x.is_cuda and not (sink is not None and getattr(sink, "_auto", False))
+
+    def forward(self, main_input):
+        auto_attach(self)   # WORLD_SIZE > 1: data-parallel gradient averaging without touching train.py
+        if self._overlap_ok(main_input):
+            # The token path needs x2 only; layer3, layer4 and fc1 need nothing of it.  Its kernels (2016 tokens) are
+            # far too small to fill the GPU, so it runs on its own stream next to layer3/layer4 — and autograd runs
+            # each node's backward on its forward's stream, so the two backwards overlap the same way.
+            main = torch.cuda.current_stream()
+            ts = _token_stream(main_input.device)
+            x1, x2 = self.main_encoder.first_half(main_input)
+            ts.wait_stream(main)
+            with torch.cuda.stream(ts):
+                feat_visual, feat_out, pl_term = self._token_path(x2)
+            x2.record_stream(ts)
+            main_feat, x3, x4 = self.main_encoder.second_half(x2)
+            main.wait_stream(ts)
+            for t in (feat_visual, feat_out, pl_term):
+                if t is not None:
+                    t.record_stream(main)
+        else:
+            main_feat, x1, x2, x3, x4 = self.main_encoder(main_input)
+            feat_visual, feat_out, pl_term = self._token_path(x2)
+        B = feat_visual.size(0)
+        pred_params = _RegressorFn.apply(main_feat, feat_out.reshape(B, -1), self.mean_params.reshape(-1),
+                                         self.regressor.weight, self.regressor.bias, self.iteration)
+        if self.pl:
             return pred_params, feat_visual, pl_term
         return pred_params, feat_visual
 

@@ -72,11 +72,11 @@ SUBSAMPLE = os.environ.get("SCAT_SUBSAMPLE", "1") != "0"   # pack the input of t
 SIDE_WGRAD = os.environ.get("SCAT_SIDE_WGRAD", "1") != "0"   # bench.py clears it for its serialized, per-kernel-timed step
 
 
-def _side_stream(device):
-    """One side stream per device for the weight-gradient contractions (SCAT_SIDE_WGRAD=0 disables)."""
+def _side_stream(device, who="backbone"):
+    """One side stream per device (and user) for the weight-gradient contractions (SCAT_SIDE_WGRAD=0 disables)."""
     if not SIDE_WGRAD:
         return None
-    key = str(device)
+    key = (str(device), who)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
@@ -86,8 +86,14 @@ class _BackboneFn(torch.autograd.Function):
     """ResNet.forward (models/resnet.py:142-162) + its whole backward as one node."""
 
     @staticmethod
-    def forward(ctx, x, net, *params):
+    def forward(ctx, x, net, part, *params):
+        """part 0: the whole backbone, x = image -> (feat, x1, x2, x3, x4).
+        part 1: stem + layer1 + layer2, x = image -> (x1, x2);  part 2: layer3 + layer4 + head, x = x2 ->
+        (feat, x3, x4).  The two halves let a caller run what depends only on x2 (the token path of hand_net)
+        on another stream next to layer3/layer4, forward and backward."""
         training = net.training
+        lids = {0: (0, 1, 2, 3), 1: (0, 1), 2: (2, 3)}[part]
+        ctx.part = part
         # outputs the caller never uses (x1, x3, x4 on the reg_transformer path) must come back as None, not as
         # zero-filled tensors that the backward would then add stage by stage (424 MB of fills + 1.3 GB of axpy)
         ctx.set_materialize_grads(False)
@@ -95,13 +101,18 @@ class _BackboneFn(torch.autograd.Function):
         tape = []
         _NBT.clear()
         wp = net._wprep
-        wp.run(training)       # one launch re-lays every convolution weight for this step (ops.WeightPrep)
-        # stem: conv7x7/2 -> [BN -> ReLU -> maxpool fused]
-        c0 = ops.conv2d_fwd(x, net.conv1.weight, 2, 3)
-        s0 = _BNState(c0, net.bn1, training)
-        cur, idx0 = ops.maxpool_fwd(c0, s0.scale, s0.shift, True)
+        if part != 2:
+            wp.run(training)       # one launch re-lays every convolution weight for this step (ops.WeightPrep)
+            # stem: conv7x7/2 -> [BN -> ReLU -> maxpool fused]
+            c0 = ops.conv2d_fwd(x, net.conv1.weight, 2, 3)
+            s0 = _BNState(c0, net.bn1, training)
+            cur, idx0 = ops.maxpool_fwd(c0, s0.scale, s0.shift, True)
+        else:
+            c0 = s0 = idx0 = None
+            cur = x
         feats = []
-        for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+        all_layers = (net.layer1, net.layer2, net.layer3, net.layer4)
+        for layer in [all_layers[i] for i in lids]:
             for blk in layer:
                 xin = cur
                 c1 = ops.conv2d_fwd(xin, blk.conv1.weight, 1, 0, wp=wp)
@@ -134,9 +145,12 @@ class _BackboneFn(torch.autograd.Function):
         if _NBT:
             torch._foreach_add_(_NBT, 1)
             _NBT.clear()
-        pooled = ops.avgpool_fwd(cur, relu=True)                      # AvgPool2d(7) -> view -> relu
-        fc = ops.linear_fwd(pooled, net.fc1.weight, net.fc1.bias)
-        feat = ops.relu_fwd(fc)
+        if part != 1:
+            pooled = ops.avgpool_fwd(cur, relu=True)                      # AvgPool2d(7) -> view -> relu
+            fc = ops.linear_fwd(pooled, net.fc1.weight, net.fc1.bias)
+            feat = ops.relu_fwd(fc)
+        else:
+            pooled = feat = None
         if training and any(ctx.needs_input_grad):
             # Tensors that are also OUTPUTS of this node (x1..x4) go through save_for_backward (no
             # ctx<->output reference cycle); the tape keeps their index instead.
@@ -149,23 +163,36 @@ class _BackboneFn(torch.autograd.Function):
             ctx.net = net
             ctx.stem = (x, c0, s0, idx0)
             ctx.tail = (pooled,)
-            ctx.save_for_backward(feat, *feats)
+            if feat is not None:
+                ctx.save_for_backward(feat, *feats)
+            else:
+                ctx.save_for_backward(*feats)
         else:
             ctx.net = None
-        return (feat, *feats)
+        return (feat, *feats) if feat is not None else tuple(feats)
 
     @staticmethod
-    def backward(ctx, dfeat, dx1, dx2, dx3, dx4):
+    def backward(ctx, *douts):
         net = ctx.net
         if net is None:
             raise RuntimeError("scat_amd: backbone backward needs a training-mode forward (BN batch statistics)")
-        feat, *outs = ctx.saved_tensors
+        part = ctx.part
+        lids = {0: (0, 1, 2, 3), 1: (0, 1), 2: (2, 3)}[part]
+        if part == 1:
+            dfeat, feat, outs = None, None, list(ctx.saved_tensors)
+            stage_grads = dict(zip(lids, douts))
+        else:
+            dfeat = douts[0]
+            feat, *outs = ctx.saved_tensors
+            stage_grads = dict(zip(lids, douts[1:]))
         (pooled,) = ctx.tail
         wp = net._wprep            # data-gradient weights were re-laid with the forward ones at the start of the step
         tape = [tuple(outs[v] if isinstance(v, int) else v for v in rec) for rec in ctx.tape]
         sink = getattr(net, "_grad_sink", None)   # flat gradient buckets (scat_amd.dp.GradBuckets), or None
         grads = {}
-        if sink is not None:
+        if sink is not None and part != 2:
+            # (split backbone: the token path's backward overlaps layer4/layer3 — the head gradients are final when
+            # the first half's backward starts, which waits for the token path's input gradient)
             sink.begin_backbone()
 
         def gbuf(p):
@@ -177,7 +204,7 @@ class _BackboneFn(torch.autograd.Function):
         # Weight gradients are off the critical path (nothing in this backward reads them): they run on a side
         # stream, so their ramp-up/tail and the HBM-bound BatchNorm passes of the next layer overlap.
         main = torch.cuda.current_stream()
-        side = _side_stream(dfeat.device if dfeat is not None else outs[0].device)
+        side = _side_stream(outs[0].device)
 
         def wgrad(dy, x, w, stride, pad, sc=None, sh=None, relu=False):
             out = gbuf(w)
@@ -215,10 +242,11 @@ class _BackboneFn(torch.autograd.Function):
         # — dc3 is never written or re-read (SCAT_BNB=0: materialise it, the general path)
         use_bnb = BNB and ops.get_math_mode() == 1
 
-        stage_grads = [dx1, dx2, dx3, dx4]
         # ---- tail: relu(fc1(relu(avgpool(x4))))
         x4 = tape[-1][-2]          # (block output; the last entry is its sign mask)
-        if dfeat is not None:
+        if part == 1:
+            dcur = None
+        elif dfeat is not None:
             dfc = ops.relu_bwd(dfeat if dfeat.is_contiguous() else dfeat.contiguous(), feat)
             put(net.fc1.weight, ops.linear_wgrad(dfc, pooled, out=gbuf(net.fc1.weight)))
             put(net.fc1.bias, ops.colsum(dfc, out=gbuf(net.fc1.bias)))
@@ -229,15 +257,23 @@ class _BackboneFn(torch.autograd.Function):
             if sink is not None:     # the flat bucket is all-reduced as a whole: an unused head still owes it zeros
                 gbuf(net.fc1.weight).zero_()
                 gbuf(net.fc1.bias).zero_()
-        if sink is not None:
+        if sink is not None and part != 1:
             sink.ready(("fc1",))
         # ---- residual stages, last block first
         layers = (net.layer1, net.layer2, net.layer3, net.layer4)
-        li = 3
+        def add_ext(dcur, ext, like):
+            """gradient entering a stage = what the stages above passed down + the caller's gradient of that stage's
+            output (an incoming gradient is never modified in place: the masking below works on our own tensor)"""
+            if ext is None:
+                return dcur if dcur is not None else torch.zeros_like(like)
+            ext = ext if ext.is_contiguous() else ext.contiguous()
+            if dcur is None:
+                return ext.clone()
+            return ops.axpy(dcur, ext, 1.0, out=dcur)
+
+        li = lids[-1]
         remaining = len(layers[li])
-        ext = stage_grads[li]
-        if ext is not None:
-            dcur = ops.axpy(dcur, ext.contiguous(), 1.0, out=dcur)
+        dcur = add_ext(dcur, stage_grads[li], x4)
         for rec in reversed(tape):
             blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out, omask = rec
             # out = relu(bn3(c3) + res): g = dcur * (out>0) is also the residual branch's gradient
@@ -309,11 +345,16 @@ class _BackboneFn(torch.autograd.Function):
                     join()       # the all-reduce stream orders itself after the CURRENT stream only
                     sink.ready(("layer%d" % (li + 1),))
                 li -= 1
-                if li >= 0:
+                if li >= lids[0]:
                     remaining = len(layers[li])
-                    ext = stage_grads[li]
-                    if ext is not None:
-                        dcur = ops.axpy(dcur, ext.contiguous(), 1.0, out=dcur)
+                    dcur = add_ext(dcur, stage_grads[li], dcur)
+        if part == 2:
+            # second half: dcur is the gradient of its input x2; its buckets are done, the first half adopts them all
+            join()
+            ctx.tape = ctx.stem = ctx.tail = None
+            if sink is not None:
+                return (dcur, None, None, *[None for _ in net._flat_params])
+            return (dcur, None, None, *[grads.get(p) for p in net._flat_params])
         # ---- stem: maxpool <- relu <- bn1 <- conv1
         x, c0, s0, idx0 = ctx.stem
         da0 = ops.maxpool_bwd(dcur, idx0, tuple(c0.shape))
@@ -329,8 +370,8 @@ class _BackboneFn(torch.autograd.Function):
             # hand them to the parameters directly instead of through AccumulateGrad copies
             sink.ready(("stem",))
             sink.adopt(net._flat_params)
-            return (None, None, *[None for _ in net._flat_params])
-        return (None, None, *[grads.get(p) for p in net._flat_params])
+            return (None, None, None, *[None for _ in net._flat_params])
+        return (None, None, None, *[grads.get(p) for p in net._flat_params])
 
 
 class ResNet(nn.Module):
@@ -373,7 +414,18 @@ class ResNet(nn.Module):
             # AvgPool2d(7)+fc1(2048) fix the geometry to 224x224 in the reference too (resnet.py:115-116)
             raise RuntimeError(f"scat_amd ResNet expects 224x224 input like the reference, got {tuple(x.shape)}")
         self._flat_params = list(self.parameters())
-        return _BackboneFn.apply(x, self, *self._flat_params)
+        return _BackboneFn.apply(x, self, 0, *self._flat_params)
+
+    # The same network as two autograd nodes, for callers that overlap x2-only work with layer3/layer4
+    # (hand_net.EncoderTransformer): first_half(x) -> (x1, x2); second_half(x2) -> (feat, x3, x4).
+    def first_half(self, x):
+        if x.shape[-1] != 224 or x.shape[-2] != 224:
+            raise RuntimeError(f"scat_amd ResNet expects 224x224 input like the reference, got {tuple(x.shape)}")
+        self._flat_params = list(self.parameters())
+        return _BackboneFn.apply(x, self, 1, *self._flat_params)
+
+    def second_half(self, x2):
+        return _BackboneFn.apply(x2, self, 2, *self._flat_params)
 
 
 def _make(layers, pretrained, **kwargs):
