@@ -72,6 +72,31 @@ def _token_stream(device):
     return _TOKEN_STREAMS[key]
 
 
+def _backbone_with_tokens(backbone, main_input, token_path):
+    """-> (main_feat, token_path(x2)).  The token path of the ResNet wrappers needs x2 only; layer3, layer4 and fc1
+    need nothing of it.  Its kernels (2016 tokens at batch 96) are far too small to fill the GPU, so it runs on its
+    own stream next to layer3/layer4 — and autograd runs each node's backward on its forward's stream, so the two
+    backwards overlap the same way.  (Unattended data-parallel mode reduces the head bucket from parameter hooks on
+    whatever stream they fire: it keeps the single-stream schedule.)"""
+    sink = getattr(backbone, "_grad_sink", None)
+    if not (OVERLAP_TOKENS and main_input.is_cuda) or (sink is not None and getattr(sink, "_auto", False)):
+        main_feat, x1, x2, x3, x4 = backbone(main_input)
+        return main_feat, token_path(x2)
+    main = torch.cuda.current_stream()
+    ts = _token_stream(main_input.device)
+    x1, x2 = backbone.first_half(main_input)
+    ts.wait_stream(main)
+    with torch.cuda.stream(ts):
+        outs = token_path(x2)
+    x2.record_stream(ts)
+    main_feat, x3, x4 = backbone.second_half(x2)
+    main.wait_stream(ts)
+    for t in outs:
+        if isinstance(t, torch.Tensor):
+            t.record_stream(main)
+    return main_feat, outs
+
+
 class _TokensFn(torch.autograd.Function):
     """x + pe, then rows ``masked`` <- mask_token (models/hand_net.py:366-373), one pass."""
 
@@ -194,22 +219,30 @@ class EncoderTransformerCoarse(nn.Module):
 
     def forward(self, main_input):
         auto_attach(self)
-        main_feat, x1, x2, x3, x4 = self.main_encoder(main_input)
-        feat_visual = self.conv1x1_channel_reduction(x2)
+
+        def token_path(x2):
+            feat_visual = self.conv1x1_channel_reduction(x2)
+            B = feat_visual.size(0)
+            midx = self._draw_mask(feat_visual.device)
+            pe = self.positionalEncoding.pe[0] if self.pos_embed else None
+            tokens = _TokensFn.apply(feat_visual.view(B, 21, -1), pe, self.mask_token, midx)
+            self.transformer._holder.want_tape = bool(self.pl)
+            feat_out, attn = self.transformer(tokens, None)
+            pl_term = None
+            if self.pl:
+                dtok = self.transformer.input_grad(torch.ones_like(feat_out))
+                pl_term = ops.tokens_bwd(dtok.contiguous(), midx, want_dmask=False)[0].view_as(feat_visual)
+            return feat_visual, feat_out, attn, pl_term
+
+        main_feat, (feat_visual, feat_out, attn, pl_term) = _backbone_with_tokens(self.main_encoder, main_input,
+                                                                                  token_path)
         B = feat_visual.size(0)
-        midx = self._draw_mask(feat_visual.device)
-        pe = self.positionalEncoding.pe[0] if self.pos_embed else None
-        tokens = _TokensFn.apply(feat_visual.view(B, 21, -1), pe, self.mask_token, midx)
-        self.transformer._holder.want_tape = bool(self.pl)
-        feat_out, attn = self.transformer(tokens, None)
         mean = self.mean_params.reshape(-1)
         # joints: mean template + offsets, root-relative (no refinement loop on this variant: iters = 0)
         joints = _RegressorFn.apply(main_feat, feat_out.reshape(B, -1), mean, self._dummy_w(), self._dummy_b(), 0)
         cameras = self.regressor(torch.cat((main_feat, mean[:3].expand(B, 3)), dim=1))   # hand_net.py:296
         pred_params = torch.cat((cameras, joints[:, 3:]), dim=1)
         if self.pl:
-            dtok = self.transformer.input_grad(torch.ones_like(feat_out))
-            pl_term = ops.tokens_bwd(dtok.contiguous(), midx, want_dmask=False)[0].view_as(feat_visual)
             return pred_params, feat_visual, attn, pl_term
         return pred_params, feat_visual, attn
 
@@ -279,33 +312,10 @@ class EncoderTransformer(nn.Module):
             pl_term = ops.tokens_bwd(dtok.contiguous(), midx, want_dmask=False)[0].view_as(feat_visual)
         return feat_visual, feat_out, pl_term
 
-    def _overlap_ok(self, x):
-        # (unattended data-parallel mode reduces the head bucket from parameter hooks on whatever stream they fire:
-        # it keeps the single-stream schedule)
-        sink = getattr(self.main_encoder, "_grad_sink", None)
-        return OVERLAP_TOKENS and x.is_cuda and not (sink is not None and getattr(sink, "_auto", False))
-
     def forward(self, main_input):
         auto_attach(self)   # WORLD_SIZE > 1: data-parallel gradient averaging without touching train.py
-        if self._overlap_ok(main_input):
-            # The token path needs x2 only; layer3, layer4 and fc1 need nothing of it.  Its kernels (2016 tokens) are
-            # far too small to fill the GPU, so it runs on its own stream next to layer3/layer4 — and autograd runs
-            # each node's backward on its forward's stream, so the two backwards overlap the same way.
-            main = torch.cuda.current_stream()
-            ts = _token_stream(main_input.device)
-            x1, x2 = self.main_encoder.first_half(main_input)
-            ts.wait_stream(main)
-            with torch.cuda.stream(ts):
-                feat_visual, feat_out, pl_term = self._token_path(x2)
-            x2.record_stream(ts)
-            main_feat, x3, x4 = self.main_encoder.second_half(x2)
-            main.wait_stream(ts)
-            for t in (feat_visual, feat_out, pl_term):
-                if t is not None:
-                    t.record_stream(main)
-        else:
-            main_feat, x1, x2, x3, x4 = self.main_encoder(main_input)
-            feat_visual, feat_out, pl_term = self._token_path(x2)
+        main_feat, (feat_visual, feat_out, pl_term) = _backbone_with_tokens(self.main_encoder, main_input,
+                                                                            self._token_path)
         B = feat_visual.size(0)
         pred_params = _RegressorFn.apply(main_feat, feat_out.reshape(B, -1), self.mean_params.reshape(-1),
                                          self.regressor.weight, self.regressor.bias, self.iteration)
@@ -350,15 +360,19 @@ class EncoderPerformer(nn.Module):
 
     def forward(self, main_input):
         auto_attach(self)
-        main_feat, x1, x2, x3, x4 = self.main_encoder(main_input)
-        feat_visual = self.conv1x1_channel_reduction(x2)
+
+        def token_path(x2):
+            feat_visual = self.conv1x1_channel_reduction(x2)
+            B = feat_visual.size(0)
+            midx = self._draw_mask(feat_visual.device)
+            pe = self.positionalEncoding.pe[0] if self.pos_embed else None
+            tok = _TokensFn.apply(feat_visual.view(B, 21, -1), pe, self.mask_token, midx)
+            for blk in self.blocks:
+                tok = blk(tok)
+            return feat_visual, self.to_offsets(tok)                         # [B,21,28,28], [B,21,3]
+
+        main_feat, (feat_visual, feat_out) = _backbone_with_tokens(self.main_encoder, main_input, token_path)
         B = feat_visual.size(0)
-        midx = self._draw_mask(feat_visual.device)
-        pe = self.positionalEncoding.pe[0] if self.pos_embed else None
-        tok = _TokensFn.apply(feat_visual.view(B, 21, -1), pe, self.mask_token, midx)
-        for blk in self.blocks:
-            tok = blk(tok)
-        feat_out = self.to_offsets(tok)                                       # [B,21,3]
         pred_params = _RegressorFn.apply(main_feat, feat_out.reshape(B, -1), self.mean_params.reshape(-1),
                                          self.regressor.weight, self.regressor.bias, self.iteration)
         return pred_params, feat_visual
