@@ -68,6 +68,15 @@ class _BasicBlockFn(torch.autograd.Function):
 import os
 
 FUSED_BASIC = os.environ.get("SCAT_HRNET_FUSED", "1") != "0"   # 0: the per-layer autograd path, for A/B runs
+PARALLEL_BRANCHES = os.environ.get("SCAT_HRNET_PAR", "1") != "0"   # one stream per resolution branch of a stage
+_BRANCH_STREAMS = {}
+
+
+def _branch_stream(device, i):
+    key = (str(device), i)
+    if key not in _BRANCH_STREAMS:
+        _BRANCH_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _BRANCH_STREAMS[key]
 
 
 class Bottleneck(nn.Module):
@@ -151,15 +160,44 @@ class StageModule(nn.Module):
                     self.fuse_layers[-1].append(nn.Sequential(*chain))
         self.relu = snn.ReLU(inplace=True)
 
+    def _fuse(self, i, x):
+        acc = self.fuse_layers[i][0](x[0])
+        for j in range(1, len(self.branches)):
+            acc = snn.add(acc, self.fuse_layers[i][j](x[j]))
+        return self.relu(acc)
+
     def forward(self, x):
         assert len(self.branches) == len(x)
-        x = [branch(b) for branch, b in zip(self.branches, x)]
-        fused = []
-        for i in range(len(self.fuse_layers)):
-            acc = self.fuse_layers[i][0](x[0])
-            for j in range(1, len(self.branches)):
-                acc = snn.add(acc, self.fuse_layers[i][j](x[j]))
-            fused.append(self.relu(acc))
+        n, nout = len(self.branches), len(self.fuse_layers)
+        if not (PARALLEL_BRANCHES and n > 1 and x[0].is_cuda):
+            x = [branch(b) for branch, b in zip(self.branches, x)]
+            return [self._fuse(i, x) for i in range(nout)]
+        # The branches of a stage are independent until the exchange, each does the same number of FLOPs
+        # (channels double, pixels quarter) and none of them fills the GPU on its own — the low-resolution ones are
+        # a few dozen workgroups per kernel.  Branch i runs on stream i (stream 0 = the caller's), so does exchange
+        # output i; autograd replays each node's backward on its forward stream, so the backward overlaps the same way.
+        main = torch.cuda.current_stream()
+        sts = [main] + [_branch_stream(x[0].device, i) for i in range(1, max(n, nout))]
+        outs = [None] * n
+        for i in range(n - 1, -1, -1):
+            if i:
+                sts[i].wait_stream(main)
+            with torch.cuda.stream(sts[i]):
+                outs[i] = self.branches[i](x[i])
+            if i:
+                x[i].record_stream(sts[i])
+        fused = [None] * nout
+        for i in range(nout - 1, -1, -1):
+            for j in range(n):
+                if j != i:
+                    sts[i].wait_stream(sts[j])
+                    outs[j].record_stream(sts[i])
+            with torch.cuda.stream(sts[i]):
+                fused[i] = self._fuse(i, outs)
+        for i in range(1, max(n, nout)):
+            main.wait_stream(sts[i])
+        for i in range(1, nout):
+            fused[i].record_stream(main)
         return fused
 
 
