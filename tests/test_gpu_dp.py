@@ -80,3 +80,74 @@ def test_unattended_two_ranks_one_gpu():
         p.join(60)
     assert all(not isinstance(w, str) for _, w in got), got
     assert sorted(r for r, _ in got) == [0, 1]
+
+
+def _worker_trainstep(rank, world, port, out):
+    """bench.py's path: scat_amd.trainer.TrainStep (explicit buckets, fused Adam) with the backbone split in two nodes
+    and the token path on its own stream — the head bucket is then reduced in the middle of the backward."""
+    try:
+        import numpy as np
+        import torch.distributed as dist
+
+        from scat_amd import synth
+        from scat_amd.dp import init_distributed
+        from scat_amd.trainer import TrainStep
+        from tests.test_gpu_model import make_encoder
+
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                          LOCAL_RANK="0", SCAT_DIST_BACKEND="gloo")
+        init_distributed()
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        x = T(synth.images(700 + rank, 4)).cuda()            # each rank its own shard
+        lab = T(synth.labels(710 + rank, 4)).cuda()
+        # local gradients of this shard: a twin with the same weights in a world of its own
+        twin = make_encoder(43)
+        twin.train()
+        solo = None
+        for r in range(world):                                # (new_group is collective: same order on every rank)
+            grp = dist.new_group([r])
+            if r == rank:
+                solo = grp
+        tts = TrainStep(twin, lr=1e-4, process_group=solo)
+        random.seed(11)
+        tts(x, lab)
+        local = tts.buckets.flat_grad.detach().cpu().clone()
+        dist.all_reduce(local)
+        local /= world
+        net = make_encoder(43)
+        net.train()
+        ts = TrainStep(net, lr=1e-4)
+        assert ts.buckets.world == world
+        random.seed(11)
+        ts(x, lab)
+        got = ts.buckets.flat_grad.detach().cpu()
+        worst = 0.0
+        for name, (a, b) in ts.buckets.ranges.items():
+            ref = local[a:b]
+            err = (got[a:b] - ref).abs().max().item() / (ref.abs().max().item() + 1e-20)
+            worst = max(worst, err)
+            assert err < 1e-5, (name, err)
+        flat = ts.buckets.flat_param.detach().cpu()
+        other = flat.clone()
+        dist.broadcast(other, src=0)
+        assert torch.equal(flat, other)                       # replicas stay bit-identical after the fused Adam step
+        out.put((rank, worst))
+        dist.destroy_process_group()
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        out.put((rank, "ERR " + repr(e) + "\n" + traceback.format_exc()))
+
+
+@pytest.mark.timeout(600)
+def test_trainstep_two_ranks_one_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_trainstep, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=500) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+    assert all(not isinstance(w, str) for _, w in got), got
+    assert sorted(r for r, _ in got) == [0, 1]
