@@ -44,6 +44,16 @@ def pose_length_term(pl_term):
     return (pl_len - pl_mean).square().mean()
 
 
+_AUX = {}
+
+
+def _aux_stream(device):
+    key = str(device)
+    if key not in _AUX:
+        _AUX[key] = torch.cuda.Stream(device=device)
+    return _AUX[key]
+
+
 class FusedAdam:
     """torch.optim.Adam(params, lr) defaults (train.py:60) as one kernel over the flat buffers."""
 
@@ -79,9 +89,26 @@ class TrainStep:
         out = self.net(inputs)                                 # train.py:158-161
         pred = out[0]
         loss, parts = scat_loss(pred, labels, self.w3d, self.w2d)
-        l_pl = pose_length_term(out[2]) if len(out) == 3 else None
-        if l_pl is not None:
-            loss = loss + 10 * l_pl                            # train.py:200-201 (no gradient)
+        # train.py:200-201 adds 10 * l_pl to the loss before backward(); l_pl has no graph (pl_term is a detached
+        # gradient), so the gradients are those of `loss` alone.  Its dozen tiny reductions are therefore issued
+        # AFTER the backward has been queued, on an auxiliary stream, instead of sitting between forward and backward.
         loss.backward()                                        # train.py:206
+        l_pl = None
+        total = loss.detach()
+        if len(out) == 3:
+            if pred.is_cuda:
+                main = torch.cuda.current_stream()
+                aux = _aux_stream(pred.device)
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    l_pl = pose_length_term(out[2])
+                    total = total + 10 * l_pl
+                out[2].record_stream(aux)
+                main.wait_stream(aux)          # (queued behind the whole backward: costs the critical path nothing)
+                l_pl.record_stream(main)
+                total.record_stream(main)
+            else:
+                l_pl = pose_length_term(out[2])
+                total = total + 10 * l_pl
         self.opt.step()                                        # train.py:209
-        return loss.detach(), parts, l_pl, pred.detach()
+        return total, parts, l_pl, pred.detach()
