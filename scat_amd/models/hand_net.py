@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import os
 import random
+import warnings
 
 import numpy as np
 import torch
@@ -63,6 +64,9 @@ def _upload_indices(idx, device):
 
 OVERLAP_TOKENS = os.environ.get("SCAT_OVERLAP_TOKENS", "1") != "0"   # token path next to layer3/layer4 (own stream)
 _TOKEN_STREAMS = {}
+# The token-path parameters get their gradients from nodes that ran on the token stream while their AccumulateGrad
+# nodes belong to the caller's stream: autograd orders the two (that is the design) and says so once per process.
+warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
 
 
 def _token_stream(device):
