@@ -79,6 +79,8 @@ class GradBuckets:
         self.model = model
         self._auto = False
         self._armed = False
+        self.tail_hook = None      # called once layer1's bucket has been issued (only the stem is left): see
+                                   # trainer.FusedAdam.early
 
     # ---- unattended mode: the unmodified train.py never calls begin_backbone()/finish() itself
     def enable_auto(self):
@@ -178,6 +180,16 @@ class GradBuckets:
     def ready(self, buckets):
         for b in buckets:
             self._allreduce(self.grad_slice(b))
+        if self.tail_hook is not None and "layer1" in buckets:
+            self.tail_hook()
+
+    def wait_pending(self):
+        """make the CURRENT stream wait for every all-reduce issued so far (and apply the 1/N of the SUM fallback)"""
+        for work, scale_t in self._pending:
+            work.wait()
+            if scale_t is not None:
+                scale_t.mul_(1.0 / self.world)
+        self._pending = []
 
     def adopt(self, params):
         """Point ``p.grad`` at the flat views the fused backward has just filled."""
@@ -194,11 +206,7 @@ class GradBuckets:
         """Make the compute stream wait for every outstanding all-reduce (host does not block on GPU)."""
         if not self._head_sent:      # no backbone backward ran (e.g. frozen backbone): still gather the head
             self.begin_backbone()
-        for work, scale_t in self._pending:
-            work.wait()
-            if scale_t is not None:
-                scale_t.mul_(1.0 / self.world)
-        self._pending = []
+        self.wait_pending()
         self._head_sent = False
 
     def zero_grad(self):

@@ -81,6 +81,7 @@ class WeightPrep:
         self.table = None          # (device uint8 tensor, njobs, nblocks)
         self.dirty = True          # weights may have changed since the last run()
         self.versions = None
+        self.fresh = False         # run_early() already re-laid the weights the next run() would
 
     def __deepcopy__(self, memo):
         return WeightPrep()     # workspaces are keyed by the original parameters' addresses
@@ -114,12 +115,33 @@ class WeightPrep:
         t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.table = (t, len(raw) // jb, blk)
 
+    def run_early(self):
+        """The owner has just updated the weights and nothing will read the old re-layouts any more (end of a train
+        step): re-lay them now — on whatever stream is current — so that the next run() has nothing to launch."""
+        if not self.entries or not WPREP or lib().scat_get_math_mode() != 1 or self.table is None:
+            return
+        if any(e[3].data_ptr() != k[0] for k, e in self.entries.items()):
+            return
+        t, nj, nblk = self.table
+        lib().scat_wprep_run(_p(t), nj, nblk, _stream())
+        for e in self.entries.values():
+            e[2] = True
+        self.versions = sum(e[3]._version for e in self.entries.values())
+        self.fresh = True
+
     def run(self, training):
         """re-lay every registered weight (one launch) if they may have changed; no-op outside split-product mode"""
         if not self.entries or not WPREP or lib().scat_get_math_mode() != 1:
             for e in self.entries.values():
                 e[2] = False
+            self.fresh = False
             return
+        if self.fresh:
+            self.fresh = False
+            if (self.table is not None and all(e[3].data_ptr() == k[0] for k, e in self.entries.items())
+                    and sum(e[3]._version for e in self.entries.values()) == self.versions):
+                self.dirty = bool(training)
+                return                   # run_early() did this step's work (nothing touched the weights since)
         dead = [k for k, e in self.entries.items() if e[3].data_ptr() != k[0]]   # the parameter moved (.to(), .cuda())
         for k in dead:
             del self.entries[k]

@@ -9,6 +9,8 @@ data-parallel runs gradient buckets are all-reduced over RCCL while backward is 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -44,6 +46,7 @@ def pose_length_term(pl_term):
     return (pl_len - pl_mean).square().mean()
 
 
+EARLY_ADAM = os.environ.get("SCAT_EARLY_ADAM", "1") != "0"
 _AUX = {}
 
 
@@ -55,7 +58,13 @@ def _aux_stream(device):
 
 
 class FusedAdam:
-    """torch.optim.Adam(params, lr) defaults (train.py:60) as one kernel over the flat buffers."""
+    """torch.optim.Adam(params, lr) defaults (train.py:60) as one kernel over the flat buffers.
+
+    With a fused backbone the update is issued in two parts: everything but the stem bucket from INSIDE the backward,
+    as soon as layer1's gradients are final (``early``, hooked into GradBuckets.ready) — on its own stream, followed
+    by the next step's weight re-layout — so that both run under the stem's backward (max-pool, BatchNorm, the 7x7
+    weight gradient: 0.8 ms in which nothing else is left to do) instead of alone at the step boundary; ``step``
+    then only updates the stem bucket."""
 
     def __init__(self, buckets: GradBuckets, lr=5e-4, betas=(0.9, 0.999), eps=1e-8):
         self.b = buckets
@@ -63,15 +72,45 @@ class FusedAdam:
         self.m = torch.zeros_like(buckets.flat_param)
         self.v = torch.zeros_like(buckets.flat_param)
         self.t = 0
+        self._early_done = False
+        self._opt_stream = None
+        backbone = getattr(buckets.model, "main_encoder", None)
+        self._wprep = getattr(backbone, "_wprep", None)
+        if EARLY_ADAM and buckets.flat_param.is_cuda and "stem" in buckets.ranges and self._wprep is not None:
+            buckets.tail_hook = self.early
 
     def zero_grad(self):
         self.b.zero_grad()
 
+    def _adam(self, a, e):
+        ops.adam(self.b.flat_param[a:e], self.b.flat_grad[a:e], self.m[a:e], self.v[a:e], self.lr, self.t,
+                 self.betas[0], self.betas[1], self.eps)
+
+    def early(self):
+        """(called from the backbone backward) update every bucket but the stem's, then re-lay the weights"""
+        if self._early_done:
+            return
+        main = torch.cuda.current_stream()
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=self.b.flat_param.device)
+        opt = self._opt_stream
+        opt.wait_stream(main)
+        with torch.cuda.stream(opt):
+            self.b.wait_pending()          # data-parallel: the all-reduces of these buckets
+            self.t += 1
+            self._adam(0, self.b.ranges["stem"][0])      # the stem is the last range of the flat buffers
+            self._wprep.run_early()
+        self._early_done = True
+
     def step(self):
         self.b.finish()            # compute stream waits for the RCCL stream here
+        if self._early_done:
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            self._adam(*self.b.ranges["stem"])
+            self._early_done = False
+            return
         self.t += 1
-        ops.adam(self.b.flat_param, self.b.flat_grad, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1],
-                 self.eps)
+        self._adam(0, self.b.flat_param.numel())
 
 
 class TrainStep:
