@@ -88,12 +88,12 @@ def _backbone_with_tokens(backbone, main_input, token_path):
         return main_feat, token_path(x2)
     main = torch.cuda.current_stream()
     ts = _token_stream(main_input.device)
-    x1, x2 = backbone.first_half(main_input)
+    x1, x2, x2b = backbone.first_half(main_input)      # (x2b: the same tensor as a second autograd output)
     ts.wait_stream(main)
     with torch.cuda.stream(ts):
         outs = token_path(x2)
     x2.record_stream(ts)
-    main_feat, x3, x4 = backbone.second_half(x2)
+    main_feat, x3, x4 = backbone.second_half(x2b)
     main.wait_stream(ts)
     for t in outs:
         if isinstance(t, torch.Tensor):

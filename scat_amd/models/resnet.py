@@ -169,6 +169,10 @@ class _BackboneFn(torch.autograd.Function):
                 ctx.save_for_backward(*feats)
         else:
             ctx.net = None
+        if part == 1:
+            # x2 twice (same storage, two autograd outputs): one for the token path, one for second_half — the two
+            # gradients then arrive separately and are combined in place on the one this module produced itself
+            return (feats[0], feats[1], feats[1].view_as(feats[1]))
         return (feat, *feats) if feat is not None else tuple(feats)
 
     @staticmethod
@@ -180,7 +184,7 @@ class _BackboneFn(torch.autograd.Function):
         lids = {0: (0, 1, 2, 3), 1: (0, 1), 2: (2, 3)}[part]
         if part == 1:
             dfeat, feat, outs = None, None, list(ctx.saved_tensors)
-            stage_grads = dict(zip(lids, douts))
+            stage_grads = {0: douts[0], 1: (douts[1], douts[2])}
         else:
             dfeat = douts[0]
             feat, *outs = ctx.saved_tensors
@@ -264,6 +268,18 @@ class _BackboneFn(torch.autograd.Function):
         def add_ext(dcur, ext, like):
             """gradient entering a stage = what the stages above passed down + the caller's gradient of that stage's
             output (an incoming gradient is never modified in place: the masking below works on our own tensor)"""
+            if isinstance(ext, tuple):      # (first half) x2's two gradients: token path, second half
+                own = getattr(net, "_own_dx2", None)
+                net._own_dx2 = None
+                ext = [e for e in ext if e is not None]
+                for e in ext:                  # start from the tensor second_half's backward allocated itself
+                    if dcur is None and own is not None and e.data_ptr() == own and e.is_contiguous():
+                        dcur = e
+                        ext = [f for f in ext if f is not e]
+                        break
+                for e in ext:
+                    dcur = add_ext(dcur, e, like)
+                return dcur if dcur is not None else torch.zeros_like(like)
             if ext is None:
                 return dcur if dcur is not None else torch.zeros_like(like)
             ext = ext if ext.is_contiguous() else ext.contiguous()
@@ -352,6 +368,7 @@ class _BackboneFn(torch.autograd.Function):
             # second half: dcur is the gradient of its input x2; its buckets are done, the first half adopts them all
             join()
             ctx.tape = ctx.stem = ctx.tail = None
+            net._own_dx2 = dcur.data_ptr()      # (first_half's backward may finish this gradient in place)
             if sink is not None:
                 return (dcur, None, None, *[None for _ in net._flat_params])
             return (dcur, None, None, *[grads.get(p) for p in net._flat_params])
@@ -417,7 +434,7 @@ class ResNet(nn.Module):
         return _BackboneFn.apply(x, self, 0, *self._flat_params)
 
     # The same network as two autograd nodes, for callers that overlap x2-only work with layer3/layer4
-    # (hand_net.EncoderTransformer): first_half(x) -> (x1, x2); second_half(x2) -> (feat, x3, x4).
+    # (hand_net.EncoderTransformer): first_half(x) -> (x1, x2, x2 again); second_half(x2) -> (feat, x3, x4).
     def first_half(self, x):
         if x.shape[-1] != 224 or x.shape[-2] != 224:
             raise RuntimeError(f"scat_amd ResNet expects 224x224 input like the reference, got {tuple(x.shape)}")
