@@ -76,6 +76,7 @@ class _BNState:
 
 _SIDE = {}
 BNB1 = os.environ.get("SCAT_BNB1", "0") != "0"   # same for bn1 -> conv1: measured slower (its passes hide under the side stream), off
+BNB_MIN_H = int(os.environ.get("SCAT_BNB_MIN_H", "28"))   # fold bn3 only where it pays: 56x56 and 28x28 planes (tools/bnb_bench.py: at 14x14 the dual-source kernels cost more than the pass they save)
 BNB = os.environ.get("SCAT_BNB", "1") != "0"   # fold bn3's backward apply into conv3's gradient kernels
 SUBSAMPLE = os.environ.get("SCAT_SUBSAMPLE", "1") != "0"   # pack the input of the 1x1/stride-2 shortcuts (stride-1 kernels)
 SIDE_WGRAD = os.environ.get("SCAT_SIDE_WGRAD", "1") != "0"   # bench.py clears it for its serialized, per-kernel-timed step
@@ -305,7 +306,7 @@ class _BackboneFn(torch.autograd.Function):
             g = dcur
             ev3 = None
             w3 = blk.conv3.weight
-            if use_bnb and omask is not None and w3.shape[0] % 16 == 0:
+            if use_bnb and omask is not None and w3.shape[0] % 16 == 0 and c3.shape[2] >= BNB_MIN_H:
                 coef3, dg, db = ops.bn_bwd_pre(dcur, c3, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
                                                gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), y_mask=omask)
                 put(blk.bn3.weight, dg), put(blk.bn3.bias, db)

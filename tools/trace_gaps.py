@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Where does the GPU wait inside a train step?  Reads a rocprofv3 --kernel-trace CSV, cuts it into steps at the Adam
-kernel (one per step), and reports per steady-state step: wall time, time with >= 1 kernel running (union of the
+"""Where does the GPU wait inside a train step?  Reads a rocprofv3 --kernel-trace CSV, cuts it into steps at the stem's
+max-pool forward (one per step), and reports per steady-state step: wall time, time with >= 1 kernel running (union of the
 kernel intervals over all queues), summed kernel time, and the idle gaps grouped by the kernel that ends them."""
 import collections
 import csv
@@ -20,7 +20,7 @@ def main():
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
     rows.sort()
-    cuts = [e for s, e, n, q in rows if "adam_kernel" in n]
+    cuts = [e for s, e, n, q in rows if "maxpool_fwd" in n]
     if len(cuts) < skip + 3:
         sys.exit(f"only {len(cuts)} steps in the trace")
     t0, t1 = cuts[skip], cuts[-1]

@@ -15,7 +15,7 @@ def short(n):
 path, first, last = sys.argv[1], sys.argv[2], sys.argv[3]
 step = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path)))
-cuts = [e for s, e, n in rows if "adam_kernel" in n]
+cuts = [e for s, e, n in rows if "maxpool_fwd" in n]      # one per step (the stem)
 t0, t1 = cuts[step], cuts[step + 1]
 win = [r for r in rows if t0 <= r[0] < t1]
 i0 = next(i for i, r in enumerate(win) if first in r[2])
