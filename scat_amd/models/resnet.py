@@ -76,6 +76,7 @@ class _BNState:
 
 _SIDE = {}
 BNB1 = os.environ.get("SCAT_BNB1", "0") != "0"   # same for bn1 -> conv1: measured slower (its passes hide under the side stream), off
+BNB1_MIN_H = int(os.environ.get("SCAT_BNB1_MIN_H", "0"))
 BNB_MIN_H = int(os.environ.get("SCAT_BNB_MIN_H", "28"))   # fold bn3 only where it pays: 56x56 and 28x28 planes (tools/bnb_bench.py: at 14x14 the dual-source kernels cost more than the pass they save)
 BNB = os.environ.get("SCAT_BNB", "1") != "0"   # fold bn3's backward apply into conv3's gradient kernels
 SUBSAMPLE = os.environ.get("SCAT_SUBSAMPLE", "1") != "0"   # pack the input of the 1x1/stride-2 shortcuts (stride-1 kernels)
@@ -327,7 +328,8 @@ class _BackboneFn(torch.autograd.Function):
             da1 = ops.conv2d_dgrad_w(dc2, blk.conv2.weight, tuple(c1.shape), blk.stride, 1, wp=wp)
             del dc2, da2
             w1 = blk.conv1.weight
-            fold1 = use_bnb and BNB1 and (c1.shape[2] * c1.shape[3]) % 4 == 0 and w1.shape[0] % 16 == 0
+            fold1 = (use_bnb and BNB1 and (c1.shape[2] * c1.shape[3]) % 4 == 0 and w1.shape[0] % 16 == 0
+                     and c1.shape[2] >= BNB1_MIN_H)
             if fold1:       # same split for bn1 -> conv1 (mask recomputed from c1: relu(bn1(c1)) was never stored)
                 coef1, dg, db = ops.bn_bwd_pre(da1, c1, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight,
                                                gbuf(blk.bn1.weight), gbuf(blk.bn1.bias))
