@@ -272,14 +272,14 @@ WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW) {
     p.stages = (B * NO + 1) / 2;
     const int tiles = cdiv(p.M, 64 * p.mi) * cdiv(p.N, 64 * p.ni);
     // measured at batch 96 (SCAT_WG_TARGET / _TARGET1 / _TARGET9 sweeps of the whole train step, where these
-    // kernels share the GPU with the data-gradient chain): ~2 workgroups per CU for 1x1, ~3 for 3x3.  (Alone on the
+    // kernels share the GPU with the data-gradient chain): ~1.5 workgroups per CU for 1x1 (384), ~3 for 3x3 (768).  (Alone on the
     // GPU the 3x3 kernel prefers ~6 — its staging is VALU-bound and more co-resident waves help — but in the step
     // the extra slab traffic and reduce work cost more: 1536 -> 768 is +1.0 % on the step.)
     static const int forced = [] { const char* e = getenv("SCAT_WG_TARGET"); return e ? atoi(e) : 0; }();
     static const int forced1 = [] { const char* e = getenv("SCAT_WG_TARGET1"); return e ? atoi(e) : 0; }();
     static const int forced9 = [] { const char* e = getenv("SCAT_WG_TARGET9"); return e ? atoi(e) : 0; }();
     const int f = KK == 1 ? (forced1 > 0 ? forced1 : forced) : (forced9 > 0 ? forced9 : forced);
-    const int target = f > 0 ? f : (KK == 1 ? 512 : 768);
+    const int target = f > 0 ? f : (KK == 1 ? 384 : 768);
     int s = cdiv(target, tiles);
     const int smax = p.stages / 24 > 0 ? p.stages / 24 : 1;   // >= 24 stages (384 pixels) per slice
     if (s > smax) s = smax;
