@@ -708,7 +708,11 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
         if (!w_ready) wprep_launch(wprep_job(w, ws, M, C, transposed, 1, 1, 1, 1, 0, 0, 1), st);
         d.w = (const float*)ws;
         d.nw = (nel * 6 + 3) / 4;
-        if (!(tuning() >= 1 && tuning() <= 3)) cfg = M > 64 ? 0 : 1;   // measured at batch 96: 64x64 never wins
+        if (!(tuning() >= 1 && tuning() <= 3)) {
+            static const int thin = [] { const char* e = getenv("SCAT_PW_THIN"); return e ? atoi(e) : 0; }();
+            cfg = M > 64 ? 0 : 1;   // measured at batch 96: 64x64 never wins
+            if (cfg == 0 && tiles(128, 128) < thin) cfg = 1;          // (SCAT_PW_THIN: 64x128 below that many tiles)
+        }
         set_kernel_label("conv1x1_split_%sx32%s", names[cfg], in_scale ? "_tf" : "");
         if (in_scale) {
             if (cfg == 0) launch_pw_split<4, 128, true>(d, dc, st);

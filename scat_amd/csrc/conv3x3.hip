@@ -502,7 +502,8 @@ extern "C" int scat_conv3x3_s1(const float* src, const float* w, float* dst, int
     d.RS = bn + 2 * (W + 1);
     if (split) {
         if (!(tuning() >= 1 && tuning() <= 3)) {         // measured at batch 96: 64x128 unless the grid gets thin
-            cfg = tiles(64, 128) >= 512 ? 1 : 2;
+            static const int thin = [] { const char* e = getenv("SCAT_C3_THIN"); return e ? atoi(e) : 512; }();
+            cfg = tiles(64, 128) >= thin ? 1 : 2;
             d.RS = (cfg == 2 ? 64 : 128) + 2 * (W + 1);
         }
         set_kernel_label("conv3x3_split_%dx%dx16%s%s", cfg == 0 ? 128 : 64, cfg == 2 ? 64 : 128, transposed ? "_dgrad" : "", in_scale ? "_tf" : "");

@@ -34,7 +34,8 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
 static inline int ew_grid(int64_t n) { return (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384); }
 
 static int bn_splits(int B, int C) {
-    int s = cdiv(2048, C);
+    static const int target = [] { const char* e = getenv("SCAT_BN_BLOCKS"); return e ? atoi(e) : 2048; }();
+    int s = cdiv(target, C);
     if (s > B) s = B;
     return s < 1 ? 1 : s;
 }
