@@ -94,7 +94,8 @@ void launch_splitk_reduce(const float* slab, float* out, int64_t n, int splits, 
 
 static int wgrad_splits(int M, int N, int K, int bm, int bn) {
     int tiles = cdiv(M, bm) * cdiv(N, bn);
-    int s = cdiv(1024, tiles);                       // aim for ~4 workgroups per CU
+    static const int target = [] { const char* e = getenv("SCAT_WG_F32_TARGET"); return e ? atoi(e) : 1024; }();
+    int s = cdiv(target, tiles);                     // aim for ~4 workgroups per CU
     int smax = K / 512 > 0 ? K / 512 : 1;            // keep >= 512 contraction steps per slice
     if (s > smax) s = smax;
     if (s > 256) s = 256;

@@ -281,7 +281,8 @@ WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW) {
     const int f = KK == 1 ? (forced1 > 0 ? forced1 : forced) : (forced9 > 0 ? forced9 : forced);
     const int target = f > 0 ? f : (KK == 1 ? 384 : 768);
     int s = cdiv(target, tiles);
-    const int smax = p.stages / 24 > 0 ? p.stages / 24 : 1;   // >= 24 stages (384 pixels) per slice
+    static const int minst = [] { const char* e = getenv("SCAT_WG_MINSTAGES"); return e ? atoi(e) : 24; }();
+    const int smax = p.stages / minst > 0 ? p.stages / minst : 1;   // >= 24 stages (384 pixels) per slice
     if (s > smax) s = smax;
     if (s > 2048) s = 2048;
     if (s < 1) s = 1;
