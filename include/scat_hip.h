@@ -159,8 +159,9 @@ int scat_bn_bwd(const float* dy, const float* x, const float* y_out, const uint8
 /* BatchNorm backward split in two so that its second half never touches memory: this call masks dy IN PLACE
  * (g = dy * mask; g is also the residual branch's gradient), reduces the per-channel sums and emits
  * coef3[3*C] = (ca | cb | cc) with  dx = ca*g + cb*x + cc;  the consumers of dx apply that while loading their
- * operand (scat_conv1x1_s1_bnb, scat_conv1x1_wgrad_bnb).  Needs HW % 4 == 0 and 16-B aligned tensors. */
-int scat_bn_bwd_pre(float* dy_g, const float* x, const float* y_out, const uint8_t* y_mask, int relu, const float* scale,
+ * operand (scat_conv1x1_s1_bnb, scat_conv1x1_wgrad_bnb).  dy_add (nullable): a second contribution to the incoming
+ * gradient, summed while loading (dy_g <- mask * (dy_g + dy_add)).  Needs HW % 4 == 0 and 16-B aligned tensors. */
+int scat_bn_bwd_pre(float* dy_g, const float* dy_add, const float* x, const float* y_out, const uint8_t* y_mask, int relu, const float* scale,
                     const float* shift, const float* save_mean, const float* save_invstd, const float* gamma,
                     float* dgamma, float* dbeta, float* coef3, int B, int C, int HW, void* ws, int64_t ws_bytes,
                     void* stream);

@@ -220,7 +220,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, i
 // replaces dy IN PLACE (it is also the residual branch's gradient), per-channel sums are reduced as above, and the
 // finalize emits the three per-channel constants of   dx = ca*g + cb*x + cc   (from dx = gamma*invstd*(g - mean(g)
 // - xhat*mean(g*xhat)), xhat = (x - mu)*invstd): ca = gamma*invstd, cb = -ca*invstd*mean(g*xhat), cc = -ca*mean(g) - cb*mu.
-__global__ __launch_bounds__(256) void bn_bwd_reduce_g_kernel(float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_g_kernel(float* __restrict__ dy, const float* __restrict__ dy2,
+                                                              const float* __restrict__ x,
                                                               const float* __restrict__ yout,
                                                               const uint8_t* __restrict__ ymask, int relu,
                                                               const float* __restrict__ scale,
@@ -240,6 +241,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_g_kernel(float* __restrict_
         float xv[4], gv[4], yv[4];
         float4 t = *(const float4*)(x + off); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
         t = *(const float4*)(dy + off); gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+        if (dy2) {      // a second contribution to the incoming gradient, added on the way in
+            t = *(const float4*)(dy2 + off); gv[0] += t.x; gv[1] += t.y; gv[2] += t.z; gv[3] += t.w;
+        }
         if (has_m) {
             const uint32_t m = ymask[off >> 2];
             yv[0] = (float)(m & 1u); yv[1] = (float)((m >> 1) & 1u); yv[2] = (float)((m >> 2) & 1u); yv[3] = (float)((m >> 3) & 1u);
@@ -517,7 +521,7 @@ extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, 
 
 // g (masked dy) overwrites dy; coef3[3*C] = (ca, cb, cc) with dx = ca*g + cb*x + cc left to the consumers
 // (scat_conv1x1_s1_bnb, scat_conv2d_wgrad_bnb).  HW % 4 == 0 and 16-B aligned tensors only.
-extern "C" int scat_bn_bwd_pre(float* dy_g, const float* x, const float* y_out, const uint8_t* y_mask, int relu,
+extern "C" int scat_bn_bwd_pre(float* dy_g, const float* dy_add, const float* x, const float* y_out, const uint8_t* y_mask, int relu,
                                const float* scale, const float* shift, const float* save_mean,
                                const float* save_invstd, const float* gamma, float* dgamma, float* dbeta,
                                float* coef3, int B, int C, int HW, void* ws, int64_t ws_bytes, void* stream) {
@@ -526,13 +530,13 @@ extern "C" int scat_bn_bwd_pre(float* dy_g, const float* x, const float* y_out, 
     SCAT_REQUIRE(B > 0 && C > 0 && HW > 0, SCAT_E_SHAPE, "scat_bn_bwd_pre: non-positive dimension");
     SCAT_REQUIRE(ws && ws_bytes >= scat_bn_ws(B, C, HW), SCAT_E_WORKSPACE, "scat_bn_bwd_pre: workspace too small");
     SCAT_REQUIRE(!(y_mask && y_out), SCAT_E_ARG, "scat_bn_bwd_pre: pass the output OR its sign mask");
-    SCAT_REQUIRE((HW & 3) == 0 && (((uintptr_t)dy_g | (uintptr_t)x | (uintptr_t)y_out) & 15) == 0, SCAT_E_SHAPE,
+    SCAT_REQUIRE((HW & 3) == 0 && (((uintptr_t)dy_g | (uintptr_t)dy_add | (uintptr_t)x | (uintptr_t)y_out) & 15) == 0, SCAT_E_SHAPE,
                  "scat_bn_bwd_pre: needs HW % 4 == 0 and 16-B aligned tensors");
     SCAT_REQUIRE(fits_i32((int64_t)B * C * HW), SCAT_E_SHAPE, "scat_bn_bwd_pre: tensor exceeds 2^31 elements");
     const int S = bn_splits(B, C);
     double* part = (double*)ws;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_reduce_g_kernel, dim3(C, S), dim3(256), 0, st, dy_g, x, y_out, y_mask, relu, scale, shift,
+    hipLaunchKernelGGL(bn_bwd_reduce_g_kernel, dim3(C, S), dim3(256), 0, st, dy_g, dy_add, x, y_out, y_mask, relu, scale, shift,
                        save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW / 4), part);
     hipLaunchKernelGGL(bn_bwd_finalize3_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
                        (double)B * HW, gamma, save_mean, save_invstd, dgamma, dbeta, coef3);

@@ -276,6 +276,11 @@ class _BackboneFn(torch.autograd.Function):
             sink.ready(("fc1",))
         # ---- residual stages, last block first
         layers = (net.layer1, net.layer2, net.layer3, net.layer4)
+        pending = [None]      # a gradient contribution not yet added to dcur (see add_ext)
+
+        def w3_ok(blk):
+            return blk.conv3.weight.shape[0] % 16 == 0
+
         def add_ext(dcur, ext, like):
             """gradient entering a stage = what the stages above passed down + the caller's gradient of that stage's
             output (an incoming gradient is never modified in place: the masking below works on our own tensor)"""
@@ -288,6 +293,10 @@ class _BackboneFn(torch.autograd.Function):
                         dcur = e
                         ext = [f for f in ext if f is not e]
                         break
+                if (dcur is not None and len(ext) == 1 and ext[0].is_contiguous() and ext[0].data_ptr() % 16 == 0
+                        and os.environ.get("SCAT_DX2_FOLD", "1") != "0"):
+                    pending[0] = ext[0]        # summed by the first BatchNorm-backward reduction on its way in
+                    return dcur
                 for e in ext:
                     dcur = add_ext(dcur, e, like)
                 return dcur if dcur is not None else torch.zeros_like(like)
@@ -304,12 +313,18 @@ class _BackboneFn(torch.autograd.Function):
         for rec in reversed(tape):
             blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out, omask = rec
             # out = relu(bn3(c3) + res): g = dcur * (out>0) is also the residual branch's gradient
+            fold3 = use_bnb and omask is not None and w3_ok(blk) and c3.shape[2] >= BNB_MIN_H
+            if pending[0] is not None and not fold3:
+                dcur = ops.axpy(dcur, pending[0], 1.0, out=dcur)
+                pending[0] = None
             g = dcur
             ev3 = None
             w3 = blk.conv3.weight
-            if use_bnb and omask is not None and w3.shape[0] % 16 == 0 and c3.shape[2] >= BNB_MIN_H:
+            if fold3:
                 coef3, dg, db = ops.bn_bwd_pre(dcur, c3, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
-                                               gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), y_mask=omask)
+                                               gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), y_mask=omask,
+                                               dy_add=pending[0])
+                pending[0] = None
                 put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
                 dw3, ev3 = wgrad_bnb(g, c3, coef3, c2, w3, s2.scale, s2.shift, True)   # g is overwritten further down
                 put(w3, dw3)

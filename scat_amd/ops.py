@@ -430,16 +430,17 @@ def bn_bwd(dy, x, y_out, relu, scale, shift, save_mean, save_invstd, gamma, dgam
 
 
 def bn_bwd_pre(dy, x, relu, scale, shift, save_mean, save_invstd, gamma, dgamma=None, dbeta=None, y_out=None,
-               y_mask=None):
+               y_mask=None, dy_add=None):
     """First half of a BatchNorm backward: dy becomes the masked gradient g IN PLACE; returns (coef3[3,C], dgamma,
-    dbeta) with dx = coef3[0]*g + coef3[1]*x + coef3[2], to be applied by conv1x1_dgrad_bnb / conv1x1_wgrad_bnb."""
-    _chk(dy, x, y_out, scale, shift, save_mean, save_invstd, gamma, dgamma, dbeta)
+    dbeta) with dx = coef3[0]*g + coef3[1]*x + coef3[2], to be applied by conv1x1_dgrad_bnb / conv1x1_wgrad_bnb.
+    dy_add: a second contribution to the incoming gradient, summed on the way in (g = mask * (dy + dy_add))."""
+    _chk(dy, x, y_out, scale, shift, save_mean, save_invstd, gamma, dgamma, dbeta, dy_add)
     B, C, H, W = x.shape
     dgamma = dgamma if dgamma is not None else torch.empty_like(gamma)
     dbeta = dbeta if dbeta is not None else torch.empty_like(gamma)
     coef3 = torch.empty((3, C), dtype=torch.float32, device=x.device)
     ws = workspace(lib().scat_bn_ws(B, C, H * W), x.device)
-    lib().scat_bn_bwd_pre(_p(dy), _p(x), _p(y_out), _p(y_mask), int(relu), _p(scale), _p(shift), _p(save_mean),
+    lib().scat_bn_bwd_pre(_p(dy), _p(dy_add), _p(x), _p(y_out), _p(y_mask), int(relu), _p(scale), _p(shift), _p(save_mean),
                           _p(save_invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(coef3), B, C, H * W, _p(ws), ws.numel(),
                           _stream())
     return coef3, dgamma, dbeta
