@@ -1,0 +1,20 @@
+"""Every scheduling switch (token stream, side streams, early Adam, prepared weights, folded BatchNorm backward,
+packed shortcut input, fused dx2 sum) on versus all of them off: the first train step must give the same loss bit for
+bit (same kernels, same summation order inside each), later steps may differ only by fp32 summation-order effects."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(600)
+def test_switches_do_not_change_the_numbers():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from tools import ab_check
+
+    a, b = ab_check.run(13, {}), ab_check.run(13, ab_check.OFF)
+    assert a[0] == b[0], (a, b)
+    for u, v in zip(a[1:], b[1:]):
+        assert abs(u - v) / abs(v) < 5e-2, (a, b)
