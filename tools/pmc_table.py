@@ -1,5 +1,10 @@
 #!/usr/bin/env python
-"""Per-kernel table of rocprofv3 --pmc counters normalised by SQ_WAVE_CYCLES (second launch of each kernel)."""
+"""Per-kernel table of rocprofv3 --pmc counters (second launch of each kernel).  SQ_WAVE_CYCLES, SQ_WAIT_* and
+SQ_ACTIVE_INST_* count quad-cycles of wave lifetime and are printed as fractions of SQ_WAVE_CYCLES (WAIT_ANY = parked on
+s_waitcnt/barrier, WAIT_INST_ANY = issue stall, ACTIVE_INST_* = issuing); SQ_INSTS_* are printed per wave quad-cycle.
+SQ_VALU_MFMA_BUSY_CYCLES counts SIMD cycles (32 per v_mfma_f32_32x32x16_bf16): MfmaUtil = that / (duration x 2.4 GHz x
+1024 SIMDs), i.e. the fraction of the chip's matrix-pipe cycles that executed an MFMA (MI355X_MICROARCH.md, cycle
+constants)."""
 import collections
 import csv
 import re
@@ -22,6 +27,9 @@ for d in sys.argv[1:]:
         if seen[short] != 2:
             continue
         wc = c.get("SQ_WAVE_CYCLES", 1.0)
-        print(f"{short}  ns={kt.get(did, 0)}")
+        util = ""
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and kt.get(did, 0):
+            util = f"  MfmaUtil={c['SQ_VALU_MFMA_BUSY_CYCLES'] / (kt[did] * 2.4 * 1024):.3f}"
+        print(f"{short}  ns={kt.get(did, 0)}{util}")
         print("   " + "  ".join(f"{k[3:] if k.startswith('SQ_') else k}={v / wc:.3f}" if k != "SQ_WAVE_CYCLES" else f"WAVE_CYCLES={v:.3g}"
                                 for k, v in sorted(c.items())))
