@@ -148,27 +148,29 @@ __global__ __launch_bounds__(256) void regressor_fwd_kernel(const float* __restr
         for (int f = tid; f < F; f += 256) fsh[f] = fb[f];
         __syncthreads();
     }
-    // two outputs per pass: twice the weight loads in flight per wavefront (the loop is latency-bound)
-    for (int j = wave; j < P; j += 8) {
-        const int j2 = j + 4;
-        const bool has2 = j2 < P;
-        const float* w0 = w + (int64_t)j * ldw;
-        const float* w1 = w + (int64_t)(has2 ? j2 : j) * ldw;
-        float s0 = 0.f, s1 = 0.f;
+    // four outputs per pass: four times the weight loads in flight per wavefront (the loop is latency-bound)
+    for (int j = wave; j < P; j += 16) {
+        const float* wr[4];
+        bool has[4];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            has[q] = j + 4 * q < P;
+            wr[q] = w + (int64_t)(has[q] ? j + 4 * q : j) * ldw;
+        }
         for (int f = lane; f < F; f += 64) {
             const float x = staged ? fsh[f] : fb[f];
-            s0 = fmaf(w0[f], x, s0);
-            s1 = fmaf(w1[f], x, s1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = fmaf(wr[q][f], x, acc[q]);
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            s0 += __shfl_xor(s0, o, 64);
-            s1 += __shfl_xor(s1, o, 64);
-        }
-        if (lane == 0) {
-            base[j] = s0 + bias[j];
-            if (has2) base[j2] = s1 + bias[j2];
-        }
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], o, 64);
+        if (lane == 0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (has[q]) base[j + 4 * q] = acc[q] + bias[j + 4 * q];
     }
     if (tid < P) {
         float v = mean[tid];
