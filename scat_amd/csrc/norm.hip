@@ -71,18 +71,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ part, int C, int S, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
-                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                   float* __restrict__ scale, float* __restrict__ shift) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0, s2 = 0;
-    for (int s = 0; s < S; ++s) {
-        s1 += part[((int64_t)c * S + s) * 2];
-        s2 += part[((int64_t)c * S + s) * 2 + 1];
-    }
+// statistics -> what forward and backward need of them (+ running-stat update, unbiased variance)
+__device__ __forceinline__ void bn_finish(int c, double s1, double s2, double count, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, float* __restrict__ rmean,
+                                          float* __restrict__ rvar, float momentum, float eps,
+                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                          float* __restrict__ scale, float* __restrict__ shift) {
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0) var = 0;
@@ -96,6 +90,62 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int C, int S
         double unb = count > 1 ? var * count / (count - 1) : var;
         rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
         rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ part, int C, int S, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int s = 0; s < S; ++s) {
+        s1 += part[((int64_t)c * S + s) * 2];
+        s2 += part[((int64_t)c * S + s) * 2 + 1];
+    }
+    bn_finish(c, s1, s2, count, gamma, beta, rmean, rvar, momentum, eps, save_mean, save_invstd, scale, shift);
+}
+
+// Statistics and finalize in ONE launch when the channels alone fill the GPU (C >= 256: one 1024-thread workgroup per
+// channel, 16 wavefronts each) — the forward is a strict dependency chain, so every launch saved is latency saved.
+template <int V>
+__global__ __launch_bounds__(1024) void bn_stats_fin_kernel(const float* __restrict__ x, int B, int C, int HW,
+                                                            FastDiv dHWv, double count,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, float momentum, float eps,
+                                                            float* __restrict__ save_mean,
+                                                            float* __restrict__ save_invstd, float* __restrict__ scale,
+                                                            float* __restrict__ shift) {
+    const int c = blockIdx.x;
+    const int hwv = HW / V;
+    double s1 = 0, s2 = 0;
+    for (int idx = threadIdx.x; idx < B * hwv; idx += 1024) {
+        const int n = (int)dHWv.div((uint32_t)idx), i = idx - n * hwv;
+        const float* p = x + ((int64_t)n * C + c) * HW + i * V;
+        if (V == 4) {
+            float4 v = *(const float4*)p;
+            s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        } else {
+            double v = *p;
+            s1 += v;
+            s2 += v * v;
+        }
+    }
+    __shared__ double sh[32];
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sh[w] = s1; sh[16 + w] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { a += sh[k]; b += sh[16 + k]; }
+        bn_finish(c, a, b, count, gamma, beta, rmean, rvar, momentum, eps, save_mean, save_invstd, scale, shift);
     }
 }
 
@@ -430,6 +480,20 @@ extern "C" int scat_bn_train_stats(const float* x, int B, int C, int HW, const f
     SCAT_REQUIRE(ws && ws_bytes >= scat_bn_ws(B, C, HW), SCAT_E_WORKSPACE, "scat_bn_train_stats: workspace too small");
     const int S = bn_splits(B, C);
     hipStream_t st = (hipStream_t)stream;
+    static const int fused_min_c = [] { const char* e = getenv("SCAT_BN_FUSED_MIN_C"); return e ? atoi(e) : 256; }();
+    if (C >= fused_min_c) {
+        const double count = (double)B * HW;
+        if ((HW & 3) == 0 && ((uintptr_t)x & 15) == 0)
+            hipLaunchKernelGGL(bn_stats_fin_kernel<4>, dim3(C), dim3(1024), 0, st, x, B, C, HW, FastDiv::make(HW / 4),
+                               count, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                               scale, shift);
+        else
+            hipLaunchKernelGGL(bn_stats_fin_kernel<1>, dim3(C), dim3(1024), 0, st, x, B, C, HW, FastDiv::make(HW),
+                               count, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                               scale, shift);
+        SCAT_LAUNCH_CHECK("scat_bn_train_stats");
+        return SCAT_OK;
+    }
     if ((HW & 3) == 0 && ((uintptr_t)x & 15) == 0)
         hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(C, S), dim3(256), 0, st, x, B, C, HW, S, FastDiv::make(HW / 4),
                            (double*)ws);
