@@ -250,6 +250,63 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
+// The same reduction with its finalize in ONE launch when the channels alone fill the GPU (one 1024-thread workgroup
+// per channel): the reduce -> finalize -> apply chain of every BatchNorm backward sits on the data-gradient critical path.
+template <int V>
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_fin_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ yout,
+                                                                 const uint8_t* __restrict__ ymask, int relu,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, int B, int C, int HW,
+                                                                 FastDiv dHWv, double count, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, float* __restrict__ coef) {
+    const int c = blockIdx.x;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const int hwv = HW / V;
+    const bool has_m = V == 4 && ymask != nullptr;
+    const bool has_y = yout != nullptr || has_m;
+    double s1 = 0, s2 = 0;
+    for (int idx = threadIdx.x; idx < B * hwv; idx += 1024) {
+        const int n = (int)dHWv.div((uint32_t)idx), i = idx - n * hwv;
+        const int64_t off = ((int64_t)n * C + c) * HW + i * V;
+        float xv[V], gv[V], yv[V];
+        if (V == 4) {
+            float4 t = *(const float4*)(x + off); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            t = *(const float4*)(dy + off); gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+            if (has_m) {
+                const uint32_t m = ymask[off >> 2];
+                yv[0] = (float)(m & 1u); yv[1] = (float)((m >> 1) & 1u); yv[2] = (float)((m >> 2) & 1u); yv[3] = (float)((m >> 3) & 1u);
+            } else if (has_y) { t = *(const float4*)(yout + off); yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w; }
+        } else {
+            xv[0] = x[off]; gv[0] = dy[off];
+            if (has_y) yv[0] = yout[off];
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            float g = bn_mask(gv[q], xv[q], has_y ? yv[q] : 0.f, has_y, relu, sc, sh);
+            s1 += g;
+            s2 += (double)g * ((xv[q] - mu) * is);
+        }
+    }
+    __shared__ double shm[32];
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { shm[w] = s1; shm[16 + w] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { a += shm[k]; b += shm[16 + k]; }
+        dbeta[c] = (float)a;
+        dgamma[c] = (float)b;
+        coef[2 * c] = (float)(a / count);
+        coef[2 * c + 1] = (float)(b / count);
+    }
+}
+
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, int S, double count,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ coef) {
@@ -561,14 +618,26 @@ extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, 
                      (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y_out | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
     SCAT_REQUIRE(!y_mask || vec, SCAT_E_SHAPE, "scat_bn_bwd: the sign mask needs HW % 4 == 0 and 16-B aligned tensors");
     SCAT_REQUIRE(!(y_mask && y_out), SCAT_E_ARG, "scat_bn_bwd: pass the output OR its sign mask");
-    if (vec)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C, S), dim3(256), 0, st, dy, x, y_out, y_mask, relu, scale,
-                           shift, save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW / 4), part);
-    else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C, S), dim3(256), 0, st, dy, x, y_out, nullptr, relu, scale,
-                           shift, save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW), part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
-                       (double)B * HW, dgamma, dbeta, coef);
+    static const int fused_min_c = [] { const char* e = getenv("SCAT_BN_FUSED_MIN_C"); return e ? atoi(e) : 256; }();
+    if (C >= fused_min_c) {
+        if (vec)
+            hipLaunchKernelGGL(bn_bwd_reduce_fin_kernel<4>, dim3(C), dim3(1024), 0, st, dy, x, y_out, y_mask, relu, scale,
+                               shift, save_mean, save_invstd, B, C, HW, FastDiv::make(HW / 4), (double)B * HW, dgamma,
+                               dbeta, coef);
+        else
+            hipLaunchKernelGGL(bn_bwd_reduce_fin_kernel<1>, dim3(C), dim3(1024), 0, st, dy, x, y_out, nullptr, relu, scale,
+                               shift, save_mean, save_invstd, B, C, HW, FastDiv::make(HW), (double)B * HW, dgamma, dbeta,
+                               coef);
+    } else {
+        if (vec)
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C, S), dim3(256), 0, st, dy, x, y_out, y_mask, relu, scale,
+                               shift, save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW / 4), part);
+        else
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C, S), dim3(256), 0, st, dy, x, y_out, nullptr, relu, scale,
+                               shift, save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW), part);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
+                           (double)B * HW, dgamma, dbeta, coef);
+    }
     if (vec) {
         const int64_t nv = total / 4;
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(nv)), dim3(256), 0, st, dy, x, y_out, y_mask, relu,
