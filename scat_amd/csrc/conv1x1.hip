@@ -459,6 +459,217 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
     store_tile<1, NI, BM, BN, WM, WN>(acc, dc, d.M, d.npix, i0, j0, 0);
 }
 
+// ---------------------------------------------------------------- producer / consumer wave specialisation
+//
+// The split kernel above makes every wavefront do everything: request activations, apply the fused transform, split
+// them into bf16 terms, write LDS, read fragments, issue MFMAs.  Its instruction stream per 32-channel stage is
+// ~230 VALU + ~250 SALU + 24 LDS reads + 22 loads around 48 MFMAs, and a wavefront issues in order: the matrix pipe
+// idles while its owner splits (PMC: 0.34 busy at 2.3 wavefronts per SIMD, half of every wavefront's life spent
+// waiting to issue).  Here a 512-thread workgroup has two kinds of wavefront:
+//   * wavefronts 4-7, producers: global loads (three stages ahead) -> fused BatchNorm+ReLU -> three-way split ->
+//     LDS (two stages ahead of the readers, three buffers).  No MFMA, no LDS reads.
+//   * wavefronts 0-3, consumers: weights straight from L2 into operand registers (pre-split planes), activation
+//     fragments from LDS, MFMAs.  No staging VALU; the first fragment of the next stage is read before the barrier
+//     because that stage was published a barrier earlier.
+// One s_barrier per stage joins the two streams.  A SIMD holds one consumer and one producer per workgroup, two
+// workgroups per CU at MI = 1: the matrix pipe of a SIMD is fed by two wavefronts whose streams are MFMA + LDS
+// reads only, the VALU by two whose streams never wait for the matrix pipe.
+// DIAG (timing experiments only, results are wrong): 1 = no activation loads, 2 = no weight loads, 4 = no MFMAs,
+// 8 = no output stores, 16 = no split / LDS writes
+template <int MI, bool TF, int DIAG = 0>
+__global__ __launch_bounds__(512, (MI == 1 ? 4 : 2)) void conv1x1_pc_kernel(PwDesc d, OutDesc dc) {
+    constexpr int BN = 128, BM = 128 * MI, NI = 4, PT = 256;
+    constexpr int NIT = 4 * BN / PT;                  // k-octets per producer thread per 32-channel stage
+    constexpr int BUF = 12 * BN;                      // u32x4 per buffer: [3 planes][4 k-octets][BN]
+    extern __shared__ __align__(16) float lds[];
+    u32x4* const B0 = (u32x4*)lds;
+
+    const int mt = (d.M + BM - 1) / BM, nt = (d.npix + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int i0 = (tile % mt) * BM, j0 = (tile / mt) * BN;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nsc = (d.C + PW_KS - 1) / PW_KS;
+    const int nstage = d.ntap * nsc;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------ producer
+        const int ptid = threadIdx.x - 256;
+        const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(d.src, d.nsrc);
+        const int pcol = ptid % BN, g0 = ptid / BN;
+        const int g0u = __builtin_amdgcn_readfirstlane(g0);
+        const int chw4 = d.HW * 4;
+        int boff;
+        uint32_t pmask = 0;
+        {
+            const int j = j0 + pcol;
+            const bool bok = j < d.npix;
+            const uint32_t jj = bok ? (uint32_t)j : 0u;
+            const uint32_t n = d.dOHW.div(jj);
+            const uint32_t r = jj - n * (uint32_t)d.OHW;
+            const int oy = (int)d.dOW.div(r), ox = (int)r - oy * d.OW;
+            const int sy0 = oy * d.a + d.c0y, sx0 = ox * d.a + d.c0x;
+            boff = ((int)n * d.C * d.HW + sy0 * d.W + sx0) * 4 + 8 * g0 * chw4;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int th = t / d.KWt, tw = t - th * d.KWt;
+                const bool ok = bok && t < d.ntap && (unsigned)(sy0 + th * d.tb) < (unsigned)d.H &&
+                                (unsigned)(sx0 + tw * d.tb) < (unsigned)d.W;
+                pmask |= (ok ? 1u : 0u) << t;
+            }
+        }
+        float bst[2][NIT][8];
+        auto load_b = [&](int st, auto set_tag) {     // st >= nstage: every lane reads 0
+            constexpr int Q = decltype(set_tag)::value;
+            const int tap = st / nsc, c0 = (st - tap * nsc) * PW_KS;
+            const int th = tap / d.KWt, tw = tap - th * d.KWt;
+            const int vbase = ((pmask >> (tap < 9 ? tap : 9)) & 1u) && st < nstage ? boff + (th * d.W + tw) * d.tb * 4 : OOB;
+#pragma unroll
+            for (int r = 0; r < NIT; ++r) {
+                const int cu = c0 + 8 * (g0u + r * (PT / BN));          // wave-uniform; C % 16 == 0: whole octets
+                const int vo = cu < d.C ? vbase : OOB;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    if constexpr (DIAG & 1) bst[Q][r][m] = __int_as_float(vo + m);
+                    else
+                    bst[Q][r][m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        rsrc_b, vo, (c0 + 8 * r * (PT / BN) + m) * chw4, 0));
+                }
+            }
+        };
+        auto store_b = [&](int st, u32x4* dst, auto set_tag) {
+            constexpr int Q = decltype(set_tag)::value;
+            const int tap = st / nsc, c0 = (st - tap * nsc) * PW_KS;
+            const bool live = (pmask >> (tap < 9 ? tap : 9)) & 1u;       // padding must stay zero AFTER the transform
+            if constexpr (DIAG & 16) {
+#pragma unroll
+                for (int r = 0; r < NIT; ++r)
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(bst[Q][r][m]));
+                return;
+            }
+#pragma unroll
+            for (int r = 0; r < NIT; ++r) {
+                float x[8];
+                const int cu = c0 + 8 * (g0u + r * (PT / BN));
+                const int cc = cu < d.C ? cu : 0;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    float t = bst[Q][r][m];
+                    if constexpr (TF) {
+                        t = fmaf(t, d.scale[cc + m], d.shift[cc + m]);
+                        t = d.relu ? fmaxf(t, 0.f) : t;
+                        t = (live && cu < d.C) ? t : 0.f;
+                    }
+                    x[m] = t;
+                }
+                u32x4 hi, mid, lo;
+                split3x8(x, hi, mid, lo);
+                const int g = g0 + r * (PT / BN);
+                dst[(0 * 4 + g) * BN + pcol] = hi;
+                dst[(1 * 4 + g) * BN + pcol] = mid;
+                dst[(2 * 4 + g) * BN + pcol] = lo;
+            }
+        };
+        load_b(0, S0{});
+        load_b(1, S1{});
+        store_b(0, B0, S0{});
+        load_b(2, S0{});
+        store_b(1, B0 + BUF, S1{});
+        __syncthreads();
+        int wb = 2;                                    // buffer of stage s + 2
+        auto iter = [&](int s, auto par_tag) {
+            constexpr int P = decltype(par_tag)::value;
+            load_b(s + 3, std::integral_constant<int, P ^ 1>{});
+            store_b(s + 2, B0 + wb * BUF, par_tag);
+            wb = wb == 2 ? 0 : wb + 1;
+            __syncthreads();
+        };
+        for (int s = 0; s < nstage; s += 2) {
+            iter(s, S0{});
+            if (s + 1 < nstage) iter(s + 1, S1{});
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- consumer: rows i0 + wave*32*MI ..
+    const int l31 = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(d.w, d.nw);
+    int aoff[MI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a) {
+        const int row = i0 + (wave * MI + a) * 32 + l31;
+        aoff[a] = row < d.M ? row * 32 + lh * 16 : OOB;
+    }
+    const int aplane = d.M * 32;
+    const int nchunk = (d.C + 15) / 16;
+    auto load_a = [&](u32x4 (&dst)[MI][3], int q) {
+        const int st = q >> 1, tap = st / nsc, ch = (st - tap * nsc) * 2 + (q & 1);
+        const bool ok = ch < nchunk && st < nstage;
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                if constexpr (DIAG & 2) { dst[a][p] = u32x4{(uint32_t)q, 0x3f803f80u, (uint32_t)aoff[a], 0x3f803f80u}; }
+                else
+                dst[a][p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? aoff[a] : OOB,
+                                                                  ((tap * nchunk + ch) * 3 + p) * aplane, 0);
+            }
+    };
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int b_frag = lh * BN + l31;
+    auto read_b = [&](u32x4 (&dst)[3], const u32x4* buf, int t, int b) {
+        const u32x4* p = buf + 2 * t * BN + b_frag + b * 32;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dst[q] = p[q * 4 * BN];
+    };
+    u32x4 areg[2][MI][3];
+    u32x4 bfr[2][3];
+    load_a(areg[0], 0);
+    __syncthreads();
+    read_b(bfr[0], B0, 0, 0);
+    int rb = 0;
+    for (int s = 0; s < nstage; ++s) {
+        const u32x4* bcur = B0 + rb * BUF;
+        rb = rb == 2 ? 0 : rb + 1;
+        const u32x4* bnxt = B0 + rb * BUF;
+        static_for<2 * NI>([&](auto i_tag) {
+            constexpr int I = decltype(i_tag)::value, t = I / NI, b = I % NI;
+            if constexpr (b == 0) load_a(areg[t ^ 1], 2 * s + t + 1);
+            constexpr int fcur = I & 1, fnxt = fcur ^ 1;
+            if constexpr (b + 1 < NI) read_b(bfr[fnxt], bcur, t, b + 1);
+            else if constexpr (t == 0) read_b(bfr[fnxt], bcur, 1, 0);
+            else read_b(bfr[fnxt], bnxt, 0, 0);          // published one barrier ago
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < MI; ++a) {
+                if constexpr (DIAG & 4) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        asm volatile("" ::"v"(areg[t][a][p]));
+                        asm volatile("" ::"v"(bfr[fcur][p]));
+                    }
+                } else
+                acc[a][b] = mfma_split(areg[t][a], bfr[fcur], acc[a][b]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __syncthreads();
+    }
+    if constexpr (DIAG & 8) {
+        if (d.variant != 0x7fffffff) return;          // (never true: keeps the accumulators live)
+    }
+    store_tile<MI, NI, BM, BN, 4, 1>(acc, dc, d.M, d.npix, i0, j0, 0);
+}
+
 // ws[tap][ch][plane][i][16 bf16]: the three bf16 terms of element (i, c, tap).  w is the conv weight
 // [Cout][Cin][KH][KW]; forward: (i, c) = (co, ci); transposed (data gradient): (i, c) = (ci, co).  Tap t of the ntap
 // listed ones is (kh0 + ts*(t / KWt), kw0 + ts*(t % KWt)).  (WPrepJob in conv_common.h.)
@@ -535,6 +746,25 @@ static void launch_pw_split(const PwDesc& d, const OutDesc& dc, hipStream_t st) 
     const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, BN);
     constexpr size_t lds_bytes = (size_t)2 * 12 * BN * 16;
     hipLaunchKernelGGL((conv1x1_split_kernel<WM, BN, TF, DS>), dim3(mt * nt), dim3(NT), lds_bytes, st, d, dc);
+}
+
+// SCAT_PC: 0 = every wavefront stages and multiplies (conv1x1_split_kernel), 1 = producer/consumer wavefronts with
+// 128-row tiles, 2 = 256-row tiles where the layer has them
+static int pc_mode() {
+    static const int m = [] { const char* e = getenv("SCAT_PC"); return e ? atoi(e) : 1; }();
+    return m;
+}
+
+template <int MI, bool TF, int DIAG = 0>
+static void launch_pw_pc(const PwDesc& d, const OutDesc& dc, hipStream_t st) {
+    constexpr int BM = 128 * MI, BN = 128;
+    const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, BN);
+    constexpr size_t lds_bytes = (size_t)3 * 12 * BN * 16;
+    auto kern = conv1x1_pc_kernel<MI, TF, DIAG>;
+    static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds_bytes) == hipSuccess);
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(512), lds_bytes, st, d, dc);
 }
 
 template <int BM, int BN, bool V4, bool TF>
@@ -712,6 +942,31 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
             static const int thin = [] { const char* e = getenv("SCAT_PW_THIN"); return e ? atoi(e) : 0; }();
             cfg = M > 64 ? 0 : 1;   // measured at batch 96: 64x64 never wins
             if (cfg == 0 && tiles(128, 128) < thin) cfg = 1;          // (SCAT_PW_THIN: 64x128 below that many tiles)
+        }
+        const int pc = pc_mode();
+        if (cfg == 0 && pc) {
+            const bool big = pc == 2 && M >= 256;
+            set_kernel_label("conv1x1_split_pc%dx128x32%s", big ? 256 : 128, in_scale ? "_tf" : "");
+            if (!in_scale && !big && tuning() >= 100) {      // timing experiments (SCAT_TUNE=100+DIAG)
+                switch (tuning() - 100) {
+                case 1: launch_pw_pc<1, false, 1>(d, dc, st); break;
+                case 2: launch_pw_pc<1, false, 2>(d, dc, st); break;
+                case 4: launch_pw_pc<1, false, 4>(d, dc, st); break;
+                case 8: launch_pw_pc<1, false, 8>(d, dc, st); break;
+                case 16: launch_pw_pc<1, false, 16>(d, dc, st); break;
+                case 17: launch_pw_pc<1, false, 17>(d, dc, st); break;
+                case 3: launch_pw_pc<1, false, 3>(d, dc, st); break;
+                case 11: launch_pw_pc<1, false, 11>(d, dc, st); break;
+                case 20: launch_pw_pc<1, false, 20>(d, dc, st); break;
+                default: launch_pw_pc<1, false>(d, dc, st);
+                }
+                SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
+                return SCAT_OK;
+            }
+            if (in_scale) { if (big) launch_pw_pc<2, true>(d, dc, st); else launch_pw_pc<1, true>(d, dc, st); }
+            else { if (big) launch_pw_pc<2, false>(d, dc, st); else launch_pw_pc<1, false>(d, dc, st); }
+            SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
+            return SCAT_OK;
         }
         set_kernel_label("conv1x1_split_%sx32%s", names[cfg], in_scale ? "_tf" : "");
         if (in_scale) {

@@ -19,11 +19,29 @@ with the gloo backend (tests/test_dp_gloo.py).
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Dict, List
 
 import torch
 import torch.distributed as dist
+
+# SCAT_DP_CHECK=1: stream-ordering self-check.  zero_grad() poisons the flat gradient buffer with NaN; every bucket is
+# tested for NaN ON THE STREAM ITS COLLECTIVE IS ORDERED AFTER, immediately in front of the collective; finish() raises
+# if a bucket went out with a slice nobody had written yet (a producing stream that was not joined).
+DP_CHECK = os.environ.get("SCAT_DP_CHECK", "0") != "0"
+
+_PRODUCERS: List = []   # streams other than the caller's on which gradient kernels run (process-wide)
+
+
+def register_producer(stream):
+    """Declare a stream on which gradient kernels run besides the caller's (the weight-gradient side streams, the
+    token path's stream).  Every bucket collective is ordered after everything queued on these streams so far —
+    explicitly, by events — and not only after the stream that happens to be current when the bucket is declared
+    ready (GradBuckets._ordered_stream)."""
+    if stream is not None and all(s is not stream for s in _PRODUCERS):
+        _PRODUCERS.append(stream)
+
 
 BACKBONE_BUCKETS = ("fc1", "layer4", "layer3", "layer2", "layer1", "stem")
 
@@ -68,11 +86,20 @@ class GradBuckets:
                 off += pad(k)
             self.ranges[b] = (start, off)
         self.head_params = [p for _, p in groups["head"]]
+        self.bucket_params = {b: [p for _, p in items] for b, items in groups.items()}
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self._pending = []
         self._head_sent = False
-        self._avg_ok = True
+        self._sent = set()
+        self._comm_stream = None   # the stream every collective is ordered after (device runs only)
+        self._checks = []
+        self._host_stage = {}
+        self.check = DP_CHECK
+        self._avg_ok = False
+        if self.world > 1:
+            self._sync_replicas(model)
+            self._avg_ok = self._probe_avg()
         backbone = getattr(model, "main_encoder", None)
         if backbone is not None:
             backbone._grad_sink = self
@@ -81,6 +108,56 @@ class GradBuckets:
         self._armed = False
         self.tail_hook = None      # called once layer1's bucket has been issued (only the stem is left): see
                                    # trainer.FusedAdam.early
+
+    # ---- replica start state (what DistributedDataParallel does at construction)
+    def _sync_replicas(self, model):
+        """Every rank starts from rank 0's parameters and buffers.  The reference's train.py never seeds
+        (kaiming_normal_ / randn / default Linear init), so without this each rank would average gradients into a
+        different model.  The flat buffer makes the parameters ONE broadcast; buffers (BatchNorm running statistics,
+        num_batches_tracked, the positional table) go per dtype as one flat broadcast each."""
+        dist.broadcast(self.flat_param, src=self._src_rank(), group=self.pg)
+        by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
+        for b in model.buffers():
+            by_dtype.setdefault(b.dtype, []).append(b)
+        for dt, bufs in by_dtype.items():
+            flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+            dist.broadcast(flat, src=self._src_rank(), group=self.pg)
+            off = 0
+            for b in bufs:
+                k = b.numel()
+                b.detach().copy_(flat[off:off + k].view_as(b))
+                off += k
+
+    def _src_rank(self):
+        return dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+
+    def _probe_avg(self):
+        """ReduceOp.AVG exists in RCCL >= 2.10 only and a missing op surfaces asynchronously: ask once, on a
+        one-element tensor, synchronously."""
+        if dist.get_backend(self.pg) != "nccl":
+            return False
+        try:
+            probe = torch.ones(1, device=self.flat_grad.device)
+            dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=self.pg)
+            torch.cuda.synchronize(probe.device)
+            return bool(probe.item() == 1.0)
+        except RuntimeError:
+            return False
+
+    # ---- stream ordering of the collectives
+    def _ordered_stream(self, device):
+        """-> the stream a collective of this moment has to be ordered after: a private stream that waits for the
+        current stream and for every registered producer (an event record + wait each; the compute streams are not
+        made to wait for each other, so their overlap is untouched)."""
+        cur = torch.cuda.current_stream(device)
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=device)
+        c = self._comm_stream
+        c.wait_stream(cur)
+        for s in _PRODUCERS:
+            if s.device == c.device:
+                c.wait_stream(s)
+        return c
 
     # ---- unattended mode: the unmodified train.py never calls begin_backbone()/finish() itself
     def enable_auto(self):
@@ -117,7 +194,8 @@ class GradBuckets:
         b = self._bucket_of_param[p]
         self._have[b] += 1
         if self._have[b] == self._need[b]:
-            self._allreduce(self.grad_slice(b))
+            self._allreduce(self.grad_slice(b), b)
+            self._sent.add(b)
             if b == "head":
                 self._head_sent = True
 
@@ -128,6 +206,9 @@ class GradBuckets:
 
     # ---- views
     def view_for(self, p):
+        """the parameter's slice of the flat gradient buffer (None for a parameter that is not trained)"""
+        if p not in self.slot:
+            return None
         off, k = self.slot[p]
         return self.flat_grad[off:off + k].view_as(p)
 
@@ -136,35 +217,40 @@ class GradBuckets:
         return self.flat_grad[a:b]
 
     # ---- collectives
-    def _allreduce(self, t):
+    def _allreduce(self, t, name="?"):
         if self.world <= 1:
+            if self.check and t.is_cuda:
+                self._checks.append((name, torch.isnan(t).any()))
             return
         backend = dist.get_backend(self.pg)
-        if backend == "nccl" and self._avg_ok:   # RCCL on ROCm
-            try:
-                self._pending.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
-                return
-            except RuntimeError:
-                self._avg_ok = False             # older RCCL without AVG: sum, then scale
-        if t.is_cuda and backend != "nccl":
-            # gloo with device tensors (rehearsing N ranks on one GPU): its asynchronous device path does not order
-            # itself against HIP streams the way RCCL does (measured: buckets reduced before their last kernel had
-            # written them) — reduce synchronously; this is a test vehicle, not a performance path
-            torch.cuda.current_stream(t.device).synchronize()
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
-            t.mul_(1.0 / self.world)
+        if t.is_cuda:
+            c = self._ordered_stream(t.device)
+            with torch.cuda.stream(c):
+                if self.check:
+                    self._checks.append((name, torch.isnan(t).any()))
+                if backend == "nccl":            # RCCL: runs on the group's own stream, ordered after c
+                    op = dist.ReduceOp.AVG if self._avg_ok else dist.ReduceOp.SUM
+                    work = dist.all_reduce(t, op=op, group=self.pg, async_op=True)
+                    self._pending.append(("work", work, None if self._avg_ok else t))
+                else:
+                    # gloo with device tensors (N ranks rehearsed on one GPU): the bucket is snapshotted to pinned host
+                    # memory ON THE ORDERED STREAM — it sees exactly the bytes RCCL would read — and reduced on the
+                    # host when the step waits for its collectives.  A producer stream that was not joined shows up as
+                    # a wrong (or, under SCAT_DP_CHECK, NaN) snapshot, as it would on hardware.
+                    host = self._host_stage.get(name)
+                    if host is None or host.numel() != t.numel():
+                        host = self._host_stage[name] = torch.empty(t.numel(), dtype=t.dtype).pin_memory()
+                    host.copy_(t, non_blocking=True)
+                    ev = c.record_event()
+                    self._pending.append(("staged", (ev, host), t))
             return
-        # gloo on host tensors (CPU tests) / RCCL without AVG: SUM, scaled by 1/N in finish()
-        self._pending.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), t))
+        # gloo on host tensors (CPU tests): SUM, scaled by 1/N in wait_pending()
+        self._pending.append(("work", dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), t))
 
-    def begin_backbone(self):
-        """Called at the top of the backbone backward: head gradients are final by then (every head node is
-        nearer the loss than the backbone).  Gather them into the flat buffer and reduce them first."""
-        self._arm()
-        if self._auto and self._head_sent:
-            return          # the hooks already reduced the head bucket
+    def _gather(self, params):
+        """p.grad -> the flat views (one multi-tensor copy); a parameter without a gradient owes its bucket zeros"""
         dst, src = [], []
-        for p in self.head_params:
+        for p in params:
             v = self.view_for(p)
             if p.grad is None:
                 v.zero_()
@@ -173,19 +259,44 @@ class GradBuckets:
                 src.append(p.grad)
             p.grad = v
         if dst:
-            torch._foreach_copy_(dst, src)   # one multi-tensor launch instead of one copy per parameter
-        self._allreduce(self.grad_slice("head"))
+            torch._foreach_copy_(dst, src)
+
+    def begin_backbone(self):
+        """Called at the top of the backbone backward: head gradients are final by then (every head node is
+        nearer the loss than the backbone).  Gather them into the flat buffer and reduce them first."""
+        self._arm()
+        if self._head_sent:
+            return          # the hooks (or an earlier backbone node of this backward) already reduced the head bucket
+        backbone = getattr(self.model, "main_encoder", None)
+        for p in getattr(backbone, "_flat_params", ()):
+            v = self.view_for(p)
+            if v is not None and p.grad is not None and p.grad.data_ptr() == v.data_ptr():
+                raise RuntimeError(
+                    "scat_amd.dp: the fused backbone backward writes its weight gradients straight into the flat "
+                    "bucket (it does not accumulate): call zero_grad() before every backward — gradient accumulation "
+                    "over several backward passes is not supported with flat buckets")
+        self._gather(self.head_params)
+        self._allreduce(self.grad_slice("head"), "head")
         self._head_sent = True
+        self._sent.add("head")
 
     def ready(self, buckets):
         for b in buckets:
-            self._allreduce(self.grad_slice(b))
+            self._allreduce(self.grad_slice(b), b)
+            self._sent.add(b)
         if self.tail_hook is not None and "layer1" in buckets:
             self.tail_hook()
 
     def wait_pending(self):
         """make the CURRENT stream wait for every all-reduce issued so far (and apply the 1/N of the SUM fallback)"""
-        for work, scale_t in self._pending:
+        for kind, work, scale_t in self._pending:
+            if kind == "staged":
+                ev, host = work
+                ev.synchronize()                      # the snapshot is in host memory
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.pg)
+                host.mul_(1.0 / self.world)
+                scale_t.copy_(host, non_blocking=True)   # back into the bucket, on the waiting stream
+                continue
             work.wait()
             if scale_t is not None:
                 scale_t.mul_(1.0 / self.world)
@@ -195,23 +306,37 @@ class GradBuckets:
         """Point ``p.grad`` at the flat views the fused backward has just filled."""
         for p in params:
             v = self.view_for(p)
-            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
-                v.add_(p.grad)   # honour gradient accumulation semantics
+            if v is None:
+                continue
             p.grad = v
 
-    def backbone_done(self):
-        pass
-
     def finish(self):
-        """Make the compute stream wait for every outstanding all-reduce (host does not block on GPU)."""
-        if not self._head_sent:      # no backbone backward ran (e.g. frozen backbone): still gather the head
-            self.begin_backbone()
+        """Make the compute stream wait for every outstanding all-reduce (host does not block on GPU).  Buckets
+        nobody declared ready — a backbone without the fused-backward protocol (HRNet, a ResNet assembled from
+        scat_amd.nn modules), a frozen backbone — are gathered from ``p.grad`` and reduced here."""
+        for b in self.ranges:
+            if b in self._sent or not self.bucket_params[b]:
+                continue
+            self._gather(self.bucket_params[b])
+            self._allreduce(self.grad_slice(b), b)
         self.wait_pending()
         self._head_sent = False
+        self._sent = set()
+        if self.check and self._checks:
+            bad = [n for n, f in self._checks if bool(f.item())]
+            self._checks = []
+            if bad:
+                raise RuntimeError(f"scat_amd.dp: buckets {bad} were handed to their all-reduce before every gradient "
+                                   "in them had been written on the stream the collective is ordered after")
 
     def zero_grad(self):
+        """``p.grad = None`` for every parameter (torch's set_to_none).  The flat gradient buffer itself is not
+        cleared: every trained parameter's slice is rewritten by the next backward (fused backward: stores;
+        everything else: gathered from p.grad, zeros where there is none) — required before EVERY backward."""
         for p in self.slot:
             p.grad = None
+        if self.check:
+            self.flat_grad.fill_(float("nan"))
 
 
 def init_distributed():

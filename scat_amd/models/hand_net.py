@@ -73,6 +73,8 @@ def _token_stream(device):
     key = str(device)
     if key not in _TOKEN_STREAMS:
         _TOKEN_STREAMS[key] = torch.cuda.Stream(device=device)
+        from ..dp import register_producer
+        register_producer(_TOKEN_STREAMS[key])
     return _TOKEN_STREAMS[key]
 
 

@@ -76,6 +76,8 @@ def _branch_stream(device, i):
     key = (str(device), i)
     if key not in _BRANCH_STREAMS:
         _BRANCH_STREAMS[key] = torch.cuda.Stream(device=device)
+        from ..dp import register_producer
+        register_producer(_BRANCH_STREAMS[key])
     return _BRANCH_STREAMS[key]
 
 

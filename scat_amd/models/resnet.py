@@ -43,6 +43,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
+    def forward(self, x):
+        """models/resnet.py:78-98.  Inside ResNet the fused backbone node runs the blocks itself; this is the same
+        block executor for a block used on its own (``net.layer1[0](x)``, ``net.layer1(x)``)."""
+        return _BlockFn.apply(x, self, *self.parameters())
+
 
 def _bn_buffers(bn):
     return bn.running_mean, bn.running_var
@@ -90,7 +95,203 @@ def _side_stream(device, who="backbone"):
     key = (str(device), who)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
+        from ..dp import register_producer
+        register_producer(_SIDE[key])      # gradient kernels run here: collectives are ordered after it explicitly
     return _SIDE[key]
+
+
+def _block_forward(blk, xin, training, wp=None):
+    """Bottleneck.forward (models/resnet.py:78-98) as a kernel sequence -> tape record
+    (blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out, omask).  bn1/bn2's normalise+ReLU live in the operand load of
+    the next convolution; bn3 (+ the shortcut's BatchNorm) + residual + ReLU is the one pass that writes the output."""
+    c1 = ops.conv2d_fwd(xin, blk.conv1.weight, 1, 0, wp=wp)
+    s1 = _BNState(c1, blk.bn1, training)
+    c2 = ops.conv2d_fwd(c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True, wp=wp)
+    s2 = _BNState(c2, blk.bn2, training)
+    c3 = ops.conv2d_fwd(c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True, wp=wp)
+    s3 = _BNState(c3, blk.bn3, training)
+    if blk.downsample is not None:
+        # stride-2 shortcut: pack the pixels it reads once, then it (and its weight gradient) is a
+        # stride-1 pointwise convolution
+        xs = ops.subsample2(xin) if blk.stride == 2 and SUBSAMPLE else None
+        if xs is not None:
+            cd = ops.conv2d_fwd(xs, blk.downsample[0].weight, 1, 0, wp=wp)
+        else:
+            cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0, wp=wp)
+        sd = _BNState(cd, blk.downsample[1], training)
+        sd.xs = xs if training else None
+        res, rsc, rsh = cd, sd.scale, sd.shift      # the shortcut's BatchNorm is applied while adding
+    else:
+        cd = sd = None
+        res, rsc, rsh = xin, None, None
+    if training:    # the backward wants only the sign of the block output: keep 1 bit per element for it
+        out, omask = ops.bn_apply(c3, s3.scale, s3.shift, res, True, want_mask=True, res_scale=rsc, res_shift=rsh)
+    else:
+        out, omask = ops.bn_apply(c3, s3.scale, s3.shift, res, True, res_scale=rsc, res_shift=rsh), None
+    return (blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out, omask)
+
+
+class _Bwd:
+    """What a block's backward needs from its surroundings: where weight gradients go (flat bucket views or fresh
+    tensors), the side stream they run on, the prepared data-gradient weights."""
+
+    def __init__(self, sink, device, wp):
+        self.sink, self.wp = sink, wp
+        self.grads = {}
+        # Weight gradients are off the critical path (nothing in this backward reads them): they run on a side
+        # stream, so their ramp-up/tail and the HBM-bound BatchNorm passes of the next layer overlap.
+        self.main = torch.cuda.current_stream()
+        self.side = _side_stream(device)
+        # bn3's backward is split: its reduce masks the incoming gradient in place (that is also the residual
+        # gradient) and leaves  dc3 = ca*g + cb*c3 + cc  to conv3's two gradient kernels, which form it while loading
+        # — dc3 is never written or re-read (SCAT_BNB=0: materialise it, the general path)
+        self.use_bnb = BNB and ops.get_math_mode() == 1
+        self.pending = [None]      # a gradient contribution not yet added to dcur (see add_ext)
+
+    def gbuf(self, p):
+        return self.sink.view_for(p) if self.sink is not None else None
+
+    def put(self, p, g):
+        self.grads[p] = g
+
+    def wgrad(self, dy, x, w, stride, pad, sc=None, sh=None, relu=False):
+        out, side = self.gbuf(w), self.side
+        if side is None:
+            return ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, sc, sh, relu, out=out)
+        if out is None:
+            out = torch.empty_like(w)
+        side.wait_stream(self.main)
+        with torch.cuda.stream(side):
+            ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, sc, sh, relu, out=out, ws_slot="side")
+        dy.record_stream(side)
+        return out
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+
+    def wgrad_bnb(self, gm, z, coef, xop, w, sc=None, sh=None, relu=False):
+        """conv weight gradient from a folded BatchNorm backward; returns (dw, event after the read of gm)"""
+        out, side = self.gbuf(w), self.side
+        if side is None:
+            return ops.conv1x1_wgrad_bnb(gm, z, coef, xop, tuple(w.shape), sc, sh, relu, out=out), None
+        if out is None:
+            out = torch.empty_like(w)
+        side.wait_stream(self.main)
+        with torch.cuda.stream(side):
+            ops.conv1x1_wgrad_bnb(gm, z, coef, xop, tuple(w.shape), sc, sh, relu, out=out, ws_slot="side")
+            ev = side.record_event()
+        gm.record_stream(side)
+        coef.record_stream(side)
+        return out, ev
+
+
+def _block_backward(bc, rec, dcur):
+    """Backward of one Bottleneck from its tape record: dcur = gradient of the block output (modified in place: the
+    masked gradient is also the residual branch's gradient) -> gradient of the block input."""
+    blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out, omask = rec
+    gbuf, put, wgrad, wgrad_bnb, wp, pending = bc.gbuf, bc.put, bc.wgrad, bc.wgrad_bnb, bc.wp, bc.pending
+    # out = relu(bn3(c3) + res): g = dcur * (out>0) is also the residual branch's gradient
+    fold3 = (bc.use_bnb and omask is not None and blk.conv3.weight.shape[0] % 16 == 0
+             and c3.shape[2] >= BNB_MIN_H)
+    if pending[0] is not None and not fold3:
+        dcur = ops.axpy(dcur, pending[0], 1.0, out=dcur)
+        pending[0] = None
+    g = dcur
+    ev3 = None
+    w3 = blk.conv3.weight
+    if fold3:
+        coef3, dg, db = ops.bn_bwd_pre(dcur, c3, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
+                                       gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), y_mask=omask,
+                                       dy_add=pending[0])
+        pending[0] = None
+        put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
+        dw3, ev3 = wgrad_bnb(g, c3, coef3, c2, w3, s2.scale, s2.shift, True)   # g is overwritten further down
+        put(w3, dw3)
+        da2 = ops.conv1x1_dgrad_bnb(g, c3, coef3, w3, tuple(c2.shape), wp=wp)
+    else:
+        dc3, dg, db = ops.bn_bwd(dcur, c3, out, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
+                                 gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), dres=dcur, y_mask=omask)
+        put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
+        put(w3, wgrad(dc3, c2, w3, 1, 0, s2.scale, s2.shift, True))
+        da2 = ops.conv2d_dgrad_w(dc3, w3, tuple(c2.shape), 1, 0, wp=wp)
+        del dc3
+    dc2, dg, db = ops.bn_bwd(da2, c2, None, True, s2.scale, s2.shift, s2.mean, s2.invstd, blk.bn2.weight,
+                             gbuf(blk.bn2.weight), gbuf(blk.bn2.bias), dx=da2)
+    put(blk.bn2.weight, dg), put(blk.bn2.bias, db)
+    put(blk.conv2.weight, wgrad(dc2, c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True))
+    da1 = ops.conv2d_dgrad_w(dc2, blk.conv2.weight, tuple(c1.shape), blk.stride, 1, wp=wp)
+    del dc2, da2
+    w1 = blk.conv1.weight
+    fold1 = (bc.use_bnb and BNB1 and (c1.shape[2] * c1.shape[3]) % 4 == 0 and w1.shape[0] % 16 == 0
+             and c1.shape[2] >= BNB1_MIN_H)
+    if fold1:       # same split for bn1 -> conv1 (mask recomputed from c1: relu(bn1(c1)) was never stored)
+        coef1, dg, db = ops.bn_bwd_pre(da1, c1, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight,
+                                       gbuf(blk.bn1.weight), gbuf(blk.bn1.bias))
+        put(blk.bn1.weight, dg), put(blk.bn1.bias, db)
+        dw1, _ = wgrad_bnb(da1, c1, coef1, xin, w1)
+        put(w1, dw1)
+    else:
+        dc1, dg, db = ops.bn_bwd(da1, c1, None, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight,
+                                 gbuf(blk.bn1.weight), gbuf(blk.bn1.bias), dx=da1)
+        put(blk.bn1.weight, dg), put(blk.bn1.bias, db)
+        put(w1, wgrad(dc1, xin, w1, 1, 0))
+    if ev3 is not None:
+        bc.main.wait_event(ev3)      # the side stream's conv3 weight gradient has finished reading g
+    if cd is not None:
+        dsw, dsbn = blk.downsample[0].weight, blk.downsample[1]
+        dcd, dg, db = ops.bn_bwd(g, cd, None, False, sd.scale, sd.shift, sd.mean, sd.invstd, dsbn.weight,
+                                 gbuf(dsbn.weight), gbuf(dsbn.bias), dx=g)
+        put(dsbn.weight, dg), put(dsbn.bias, db)
+        if sd.xs is not None:
+            put(dsw, wgrad(dcd, sd.xs, dsw, 1, 0))
+        else:
+            put(dsw, wgrad(dcd, xin, dsw, blk.stride, 0))
+        dxin = None     # conv1's data gradient is written first, the shortcut's lands on top of it: at
+                        # stride 2 that touches only the even pixels (no zero fill, no read-modify-write
+                        # of the whole plane)
+    else:
+        dxin = g
+    if fold1:
+        dcur = ops.conv1x1_dgrad_bnb(da1, c1, coef1, w1, tuple(xin.shape), out=dxin, accumulate=dxin is not None,
+                                     wp=wp)
+    else:
+        dcur = ops.conv2d_dgrad_w(dc1, w1, tuple(xin.shape), 1, 0, out=dxin, accumulate=dxin is not None, wp=wp)
+    if cd is not None:
+        dcur = ops.conv2d_dgrad_w(dcd, dsw, tuple(xin.shape), blk.stride, 0, out=dcur, accumulate=True, wp=wp)
+    return dcur
+
+
+class _BlockFn(torch.autograd.Function):
+    """One Bottleneck (models/resnet.py:78-98) as an autograd node of its own: ``blk(x)`` on a block taken out of
+    the network.  The same two functions the fused backbone runs per block, so its parity is this block's parity."""
+
+    @staticmethod
+    def forward(ctx, x, blk, *params):
+        x = x if x.is_contiguous() else x.contiguous()
+        _NBT.clear()
+        rec = _block_forward(blk, x, blk.training, None)
+        if _NBT:
+            torch._foreach_add_(_NBT, 1)
+            _NBT.clear()
+        out = rec[10]
+        if blk.training and any(ctx.needs_input_grad):
+            ctx.rec = rec[:10] + (None, rec[11])       # (the output itself is not needed: the backward reads its mask)
+            ctx.params = params
+        else:
+            ctx.rec = None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.rec is None:
+            raise RuntimeError("scat_amd: Bottleneck backward needs a training-mode forward (BN batch statistics)")
+        bc = _Bwd(None, dout.device, None)
+        dcur = dout.contiguous().clone()               # masked in place below; the caller's tensor stays intact
+        dx = _block_backward(bc, ctx.rec, dcur)
+        bc.join()
+        params, ctx.rec = ctx.params, None
+        return (dx if ctx.needs_input_grad[0] else None, None, *[bc.grads.get(p) for p in params])
 
 
 class _BackboneFn(torch.autograd.Function):
@@ -125,33 +326,9 @@ class _BackboneFn(torch.autograd.Function):
         all_layers = (net.layer1, net.layer2, net.layer3, net.layer4)
         for layer in [all_layers[i] for i in lids]:
             for blk in layer:
-                xin = cur
-                c1 = ops.conv2d_fwd(xin, blk.conv1.weight, 1, 0, wp=wp)
-                s1 = _BNState(c1, blk.bn1, training)
-                c2 = ops.conv2d_fwd(c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True, wp=wp)
-                s2 = _BNState(c2, blk.bn2, training)
-                c3 = ops.conv2d_fwd(c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True, wp=wp)
-                s3 = _BNState(c3, blk.bn3, training)
-                if blk.downsample is not None:
-                    # stride-2 shortcut: pack the pixels it reads once, then it (and its weight gradient) is a
-                    # stride-1 pointwise convolution
-                    xs = ops.subsample2(xin) if blk.stride == 2 and SUBSAMPLE else None
-                    if xs is not None:
-                        cd = ops.conv2d_fwd(xs, blk.downsample[0].weight, 1, 0, wp=wp)
-                    else:
-                        cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0, wp=wp)
-                    sd = _BNState(cd, blk.downsample[1], training)
-                    sd.xs = xs if training else None
-                    res, rsc, rsh = cd, sd.scale, sd.shift      # the shortcut's BatchNorm is applied while adding
-                else:
-                    cd = sd = None
-                    res, rsc, rsh = xin, None, None
-                if training:    # the backward wants only the sign of the block output: keep 1 bit per element for it
-                    cur, omask = ops.bn_apply(c3, s3.scale, s3.shift, res, True, want_mask=True, res_scale=rsc,
-                                              res_shift=rsh)
-                else:
-                    cur, omask = ops.bn_apply(c3, s3.scale, s3.shift, res, True, res_scale=rsc, res_shift=rsh), None
-                tape.append((blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, cur, omask))
+                rec = _block_forward(blk, cur, training, wp)
+                cur = rec[10]
+                tape.append(rec)
             feats.append(cur)
         if _NBT:
             torch._foreach_add_(_NBT, 1)
@@ -204,58 +381,12 @@ class _BackboneFn(torch.autograd.Function):
         wp = net._wprep            # data-gradient weights were re-laid with the forward ones at the start of the step
         tape = [tuple(outs[v] if isinstance(v, int) else v for v in rec) for rec in ctx.tape]
         sink = getattr(net, "_grad_sink", None)   # flat gradient buckets (scat_amd.dp.GradBuckets), or None
-        grads = {}
         if sink is not None and part != 2:
             # (split backbone: the token path's backward overlaps layer4/layer3 — the head gradients are final when
             # the first half's backward starts, which waits for the token path's input gradient)
             sink.begin_backbone()
-
-        def gbuf(p):
-            return sink.view_for(p) if sink is not None else None
-
-        def put(p, g):
-            grads[p] = g
-
-        # Weight gradients are off the critical path (nothing in this backward reads them): they run on a side
-        # stream, so their ramp-up/tail and the HBM-bound BatchNorm passes of the next layer overlap.
-        main = torch.cuda.current_stream()
-        side = _side_stream(outs[0].device)
-
-        def wgrad(dy, x, w, stride, pad, sc=None, sh=None, relu=False):
-            out = gbuf(w)
-            if side is None:
-                return ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, sc, sh, relu, out=out)
-            if out is None:
-                out = torch.empty_like(w)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, sc, sh, relu, out=out, ws_slot="side")
-            dy.record_stream(side)
-            return out
-
-        def join():
-            if side is not None:
-                main.wait_stream(side)
-
-        def wgrad_bnb(gm, z, coef, xop, w, sc=None, sh=None, relu=False):
-            """conv weight gradient from a folded BatchNorm backward; returns (dw, event after the read of gm)"""
-            out = gbuf(w)
-            if side is None:
-                return ops.conv1x1_wgrad_bnb(gm, z, coef, xop, tuple(w.shape), sc, sh, relu, out=out), None
-            if out is None:
-                out = torch.empty_like(w)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                ops.conv1x1_wgrad_bnb(gm, z, coef, xop, tuple(w.shape), sc, sh, relu, out=out, ws_slot="side")
-                ev = side.record_event()
-            gm.record_stream(side)
-            coef.record_stream(side)
-            return out, ev
-
-        # bn3's backward is split: its reduce masks the incoming gradient in place (that is also the residual
-        # gradient) and leaves  dc3 = ca*g + cb*c3 + cc  to conv3's two gradient kernels, which form it while loading
-        # — dc3 is never written or re-read (SCAT_BNB=0: materialise it, the general path)
-        use_bnb = BNB and ops.get_math_mode() == 1
+        bc = _Bwd(sink, outs[0].device, wp)
+        grads, gbuf, put, wgrad, join, pending = bc.grads, bc.gbuf, bc.put, bc.wgrad, bc.join, bc.pending
 
         # ---- tail: relu(fc1(relu(avgpool(x4))))
         x4 = tape[-1][-2]          # (block output; the last entry is its sign mask)
@@ -276,11 +407,6 @@ class _BackboneFn(torch.autograd.Function):
             sink.ready(("fc1",))
         # ---- residual stages, last block first
         layers = (net.layer1, net.layer2, net.layer3, net.layer4)
-        pending = [None]      # a gradient contribution not yet added to dcur (see add_ext)
-
-        def w3_ok(blk):
-            return blk.conv3.weight.shape[0] % 16 == 0
-
         def add_ext(dcur, ext, like):
             """gradient entering a stage = what the stages above passed down + the caller's gradient of that stage's
             output (an incoming gradient is never modified in place: the masking below works on our own tensor)"""
@@ -311,77 +437,7 @@ class _BackboneFn(torch.autograd.Function):
         remaining = len(layers[li])
         dcur = add_ext(dcur, stage_grads[li], x4)
         for rec in reversed(tape):
-            blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out, omask = rec
-            # out = relu(bn3(c3) + res): g = dcur * (out>0) is also the residual branch's gradient
-            fold3 = use_bnb and omask is not None and w3_ok(blk) and c3.shape[2] >= BNB_MIN_H
-            if pending[0] is not None and not fold3:
-                dcur = ops.axpy(dcur, pending[0], 1.0, out=dcur)
-                pending[0] = None
-            g = dcur
-            ev3 = None
-            w3 = blk.conv3.weight
-            if fold3:
-                coef3, dg, db = ops.bn_bwd_pre(dcur, c3, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
-                                               gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), y_mask=omask,
-                                               dy_add=pending[0])
-                pending[0] = None
-                put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
-                dw3, ev3 = wgrad_bnb(g, c3, coef3, c2, w3, s2.scale, s2.shift, True)   # g is overwritten further down
-                put(w3, dw3)
-                da2 = ops.conv1x1_dgrad_bnb(g, c3, coef3, w3, tuple(c2.shape), wp=wp)
-            else:
-                dc3, dg, db = ops.bn_bwd(dcur, c3, out, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
-                                         gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), dres=dcur, y_mask=omask)
-                put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
-                put(w3, wgrad(dc3, c2, w3, 1, 0, s2.scale, s2.shift, True))
-                da2 = ops.conv2d_dgrad_w(dc3, w3, tuple(c2.shape), 1, 0, wp=wp)
-                del dc3
-            dc2, dg, db = ops.bn_bwd(da2, c2, None, True, s2.scale, s2.shift, s2.mean, s2.invstd, blk.bn2.weight,
-                                     gbuf(blk.bn2.weight), gbuf(blk.bn2.bias), dx=da2)
-            put(blk.bn2.weight, dg), put(blk.bn2.bias, db)
-            put(blk.conv2.weight, wgrad(dc2, c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True))
-            da1 = ops.conv2d_dgrad_w(dc2, blk.conv2.weight, tuple(c1.shape), blk.stride, 1, wp=wp)
-            del dc2, da2
-            w1 = blk.conv1.weight
-            fold1 = (use_bnb and BNB1 and (c1.shape[2] * c1.shape[3]) % 4 == 0 and w1.shape[0] % 16 == 0
-                     and c1.shape[2] >= BNB1_MIN_H)
-            if fold1:       # same split for bn1 -> conv1 (mask recomputed from c1: relu(bn1(c1)) was never stored)
-                coef1, dg, db = ops.bn_bwd_pre(da1, c1, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight,
-                                               gbuf(blk.bn1.weight), gbuf(blk.bn1.bias))
-                put(blk.bn1.weight, dg), put(blk.bn1.bias, db)
-                dw1, _ = wgrad_bnb(da1, c1, coef1, xin, w1)
-                put(w1, dw1)
-            else:
-                dc1, dg, db = ops.bn_bwd(da1, c1, None, True, s1.scale, s1.shift, s1.mean, s1.invstd, blk.bn1.weight,
-                                         gbuf(blk.bn1.weight), gbuf(blk.bn1.bias), dx=da1)
-                put(blk.bn1.weight, dg), put(blk.bn1.bias, db)
-                put(w1, wgrad(dc1, xin, w1, 1, 0))
-            if ev3 is not None:
-                main.wait_event(ev3)      # the side stream's conv3 weight gradient has finished reading g
-            if cd is not None:
-                dsw, dsbn = blk.downsample[0].weight, blk.downsample[1]
-                dcd, dg, db = ops.bn_bwd(g, cd, None, False, sd.scale, sd.shift, sd.mean, sd.invstd, dsbn.weight,
-                                         gbuf(dsbn.weight), gbuf(dsbn.bias), dx=g)
-                put(dsbn.weight, dg), put(dsbn.bias, db)
-                if sd.xs is not None:
-                    put(dsw, wgrad(dcd, sd.xs, dsw, 1, 0))
-                else:
-                    put(dsw, wgrad(dcd, xin, dsw, blk.stride, 0))
-                dxin = None     # conv1's data gradient is written first, the shortcut's lands on top of it: at
-                                # stride 2 that touches only the even pixels (no zero fill, no read-modify-write
-                                # of the whole plane)
-            else:
-                dxin = g
-            if fold1:
-                dcur = ops.conv1x1_dgrad_bnb(da1, c1, coef1, w1, tuple(xin.shape), out=dxin, accumulate=dxin is not None,
-                                             wp=wp)
-            else:
-                dcur = ops.conv2d_dgrad_w(dc1, w1, tuple(xin.shape), 1, 0, out=dxin, accumulate=dxin is not None, wp=wp)
-                del dc1
-            if cd is not None:
-                dcur = ops.conv2d_dgrad_w(dcd, dsw, tuple(xin.shape), blk.stride, 0, out=dcur, accumulate=True, wp=wp)
-                del dcd
-            del da1, g
+            dcur = _block_backward(bc, rec, dcur)
             remaining -= 1
             if remaining == 0:
                 if sink is not None:
@@ -426,12 +482,13 @@ class ResNet(nn.Module):
         self.conv1 = snn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = snn.BatchNorm2d(64)
         self.relu = snn.ReLU(inplace=True)
-        self.maxpool = nn.Identity()   # placeholder attribute; pooling runs inside the fused node
+        self.maxpool = snn.MaxPool2d(kernel_size=3, stride=2, padding=1)   # (inside forward() pooling is part of the
+                                                                            # fused node, with bn1+ReLU in its load)
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
         self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
         self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
-        self.avgpool = nn.Identity()
+        self.avgpool = snn.AvgPool2d(7)
         self.fc1 = snn.Linear(512 * block.expansion, 1024)
         self._wprep = ops.WeightPrep()   # prepared convolution weights (one re-layout launch per step)
         for m in self.modules():   # same initialisers as resnet.py:118-123
@@ -472,19 +529,51 @@ class ResNet(nn.Module):
         return _BackboneFn.apply(x2, self, 2, *self._flat_params)
 
 
-def _make(layers, pretrained, **kwargs):
-    # pretrained=True downloads ImageNet weights in the reference (resnet.py:194); there is no
-    # network on the GPU box, so weights come from load_state_dict (keys are identical).
-    return ResNet(Bottleneck, layers, **kwargs)
+def pretrained_checkpoint(name):
+    """Where ``pretrained=True`` looks for the ImageNet weights the reference downloads (resnet.py:192-195): the file
+    named by SCAT_<NAME>_CKPT (e.g. SCAT_RESNET50_CKPT), else ``$SCAT_PRETRAINED_DIR/<name>.pth``, else the torch hub
+    checkpoint cache (where model_zoo.load_url would have put it).  None if there is no such file."""
+    import glob
+
+    cand = [os.environ.get("SCAT_%s_CKPT" % name.upper())]
+    if os.environ.get("SCAT_PRETRAINED_DIR"):
+        cand.append(os.path.join(os.environ["SCAT_PRETRAINED_DIR"], name + ".pth"))
+    hub = os.path.join(os.environ.get("TORCH_HOME", os.path.expanduser("~/.cache/torch")), "hub", "checkpoints")
+    cand += sorted(glob.glob(os.path.join(hub, name + "-*.pth")))
+    for c in cand:
+        if c and os.path.isfile(c):
+            return c
+    return None
+
+
+def _make(name, layers, pretrained, **kwargs):
+    net = ResNet(Bottleneck, layers, **kwargs)
+    if pretrained:
+        # the reference downloads ImageNet weights here and loads them strict=False (resnet.py:192-195); there is no
+        # network on the GPU box: take them from a local file, and say so loudly when there is none — training the
+        # backbone from its random initialisation is a different recipe from the reference's
+        path = pretrained_checkpoint(name)
+        if path is None:
+            import warnings
+
+            warnings.warn(f"scat_amd.models.resnet.{name}(pretrained=True): no local ImageNet checkpoint found (set "
+                          f"SCAT_{name.upper()}_CKPT or SCAT_PRETRAINED_DIR, or call scat_amd.schedule."
+                          "load_pretrained_backbone): the backbone keeps its RANDOM initialisation, unlike the "
+                          "reference, which starts from ImageNet weights", RuntimeWarning, stacklevel=3)
+        else:
+            from ..schedule import load_pretrained_backbone
+
+            load_pretrained_backbone(net, path)
+    return net
 
 
 def resnet50(pretrained=False, **kwargs):
-    return _make([3, 4, 6, 3], pretrained, **kwargs)
+    return _make("resnet50", [3, 4, 6, 3], pretrained, **kwargs)
 
 
 def resnet101(pretrained=False, **kwargs):
-    return _make([3, 4, 23, 3], pretrained, **kwargs)
+    return _make("resnet101", [3, 4, 23, 3], pretrained, **kwargs)
 
 
 def resnet152(pretrained=False, **kwargs):
-    return _make([3, 8, 36, 3], pretrained, **kwargs)
+    return _make("resnet152", [3, 8, 36, 3], pretrained, **kwargs)

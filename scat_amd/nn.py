@@ -271,3 +271,57 @@ class Upsample(nn.Module):
 
     def forward(self, x):
         return _UpsampleFn.apply(x, int(self.scale_factor))
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (models/resnet.py:112): int8 arg-max kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y, idx = ops.maxpool_fwd(x)
+        ctx.save_for_backward(idx)
+        ctx.xs = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return ops.maxpool_bwd(_c(dy), idx, ctx.xs)
+
+
+class _GlobalAvgPoolFn(torch.autograd.Function):
+    """nn.AvgPool2d(k) on a k x k plane (models/resnet.py:115 on the 7x7 map) -> [B,C,1,1]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y = ops.avgpool_fwd(x, relu=False)
+        ctx.save_for_backward(y)
+        ctx.xs = tuple(x.shape)
+        return y.view(x.shape[0], x.shape[1], 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.avgpool_bwd(_c(dy.reshape(y.shape)), y, ctx.xs, relu=False)
+
+
+class MaxPool2d(nn.MaxPool2d):
+    """The one geometry the path has: 3x3, stride 2, padding 1."""
+
+    def forward(self, x):
+        if (self.kernel_size, self.stride, self.padding) != (3, 2, 1) or self.dilation != 1 or self.ceil_mode:
+            raise RuntimeError("scat_amd.nn.MaxPool2d: only kernel_size=3, stride=2, padding=1 (models/resnet.py:112)")
+        return _MaxPoolFn.apply(x)
+
+
+class AvgPool2d(nn.AvgPool2d):
+    """AvgPool2d(k) applied to a k x k map (the reference's AvgPool2d(7) on x4): a per-channel mean."""
+
+    def forward(self, x):
+        k = self.kernel_size if isinstance(self.kernel_size, int) else self.kernel_size[0]
+        if x.shape[-1] != k or x.shape[-2] != k or self.padding != 0:
+            raise RuntimeError(f"scat_amd.nn.AvgPool2d({k}): the input plane must be {k}x{k} (models/resnet.py:115), "
+                               f"got {tuple(x.shape)}")
+        return _GlobalAvgPoolFn.apply(x)

@@ -717,6 +717,9 @@ def loss_fwd_bwd(out, labels, w3d=100000.0, w2d=10.0):
     _chk(out, labels)
     B = out.shape[0]
     ld = labels.shape[1]
+    if out.dim() != 2 or out.shape[1] != 66 or labels.dim() != 2 or labels.shape[0] != B or ld not in (105, 166):
+        raise ValueError(f"loss_fwd_bwd: outputs [B,66] and labels [B,105] or [B,166] expected (train.py:188-198), got "
+                         f"{tuple(out.shape)} and {tuple(labels.shape)}")
     o3, o2 = (0, 63) if ld == 105 else (61, 124)
     losses = torch.empty((3,), dtype=torch.float32, device=out.device)
     dout = torch.empty_like(out)

@@ -134,20 +134,25 @@ class TrainStep:
         loss.backward()                                        # train.py:206
         l_pl = None
         total = loss.detach()
-        if len(out) == 3:
+        # which output is the pose-length term: EncoderTransformer returns (pred, feat_visual[, pl_term])
+        # (hand_net.py:395-398), EncoderTransformerCoarse (pred, feat_visual, attn[, pl_term]) (hand_net.py:305-311)
+        # — a [B,8,21,21] attention map in third place is not a pose-length term
+        has_pl = bool(self.net.pl) if hasattr(self.net, "pl") else len(out) == 3
+        pl_term = out[-1] if has_pl and len(out) >= 3 and out[-1].shape == out[1].shape else None
+        if pl_term is not None:
             if pred.is_cuda:
                 main = torch.cuda.current_stream()
                 aux = _aux_stream(pred.device)
                 aux.wait_stream(main)
                 with torch.cuda.stream(aux):
-                    l_pl = pose_length_term(out[2])
+                    l_pl = pose_length_term(pl_term)
                     total = total + 10 * l_pl
-                out[2].record_stream(aux)
+                pl_term.record_stream(aux)
                 main.wait_stream(aux)          # (queued behind the whole backward: costs the critical path nothing)
                 l_pl.record_stream(main)
                 total.record_stream(main)
             else:
-                l_pl = pose_length_term(out[2])
+                l_pl = pose_length_term(pl_term)
                 total = total + 10 * l_pl
         self.opt.step()                                        # train.py:209
         return total, parts, l_pl, pred.detach()

@@ -130,6 +130,65 @@ def _worker_auto(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _worker_diverged_start(rank, world, port, out):
+    """ranks construct the model from DIFFERENT seeds (the reference's train.py never seeds): attaching the buckets
+    must leave every rank with rank 0's parameters and buffers, as DistributedDataParallel does at construction;
+    a backbone without the fused-backward protocol must still get all of its buckets gathered and reduced"""
+    import torch.distributed as dist
+
+    from scat_amd.dp import GradBuckets
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1000 + rank)
+    net = _Tiny()
+    net.register_buffer("running_mean", torch.randn(7))
+    net.register_buffer("num_batches_tracked", torch.tensor(3 + rank, dtype=torch.long))
+    mine = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    b = GradBuckets(net)
+    flat = b.flat_param.clone()
+    other = flat.clone()
+    dist.broadcast(other, src=0)
+    assert torch.equal(flat, other)
+    now = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.equal(now, mine) == (rank == 0)       # rank 1's own draw is gone
+    for buf in (net.running_mean, net.num_batches_tracked.float()):
+        ref = buf.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(buf, ref)
+    assert int(net.num_batches_tracked) == 3
+    # plain autograd backbone (no ready()/adopt()): finish() gathers and reduces every bucket
+    torch.manual_seed(50 + rank)
+    x, y = torch.randn(8, 6), torch.randn(8, 3)
+    (net(x) - y).square().mean().backward()
+    local = {n: p.grad.clone() for n, p in net.named_parameters()}
+    b.finish()
+    for n, p in net.named_parameters():
+        g = local[n]
+        dist.all_reduce(g)
+        g /= world
+        assert torch.allclose(p.grad, g, atol=1e-7), n
+        assert p.grad.data_ptr() == b.view_for(p).data_ptr(), n
+    frozen = torch.nn.Parameter(torch.zeros(2), requires_grad=False)
+    assert b.view_for(frozen) is None
+    out.put((rank, 0.0))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_replicas_start_from_rank0():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_diverged_start, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(100)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in (q.get(timeout=5) for _ in range(2))) == [0, 1]
+
+
 @pytest.mark.timeout(120)
 def test_two_rank_unattended():
     ctx = mp.get_context("spawn")
@@ -166,7 +225,9 @@ def test_single_process_buckets_are_storage_only():
     b = GradBuckets(net)
     assert b.world == 1
     (net(torch.randn(4, 6)).sum()).backward()
-    b.finish()     # gathers head grads, no collective
+    b.finish()     # gathers every bucket nobody declared ready, no collective
+    for p in net.parameters():
+        assert p.grad.data_ptr() == b.view_for(p).data_ptr()
     assert net.regressor.weight.grad.data_ptr() == b.view_for(net.regressor.weight).data_ptr()
     off, k = b.slot[net.regressor.weight]
     assert off % 64 == 0     # 256-B aligned slots for the kernels' 16-B loads

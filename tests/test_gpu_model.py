@@ -394,6 +394,80 @@ def test_split_products_train_like_fp32_mfma():
         assert abs(a - b) / abs(a) < 3e-2, (l0, l1)    # init): measured 0.3 % .. 1.2 % apart, as two fp32 orders are
 
 
+@pytest.mark.parametrize("math", [1, 0])
+def test_bottleneck_golden(golden, math):
+    """G3: ONE Bottleneck(64->64->256, downsample) taken out of the network, B=4, 8x8 — small enough for
+    the gradients to be well conditioned, so the COMPOSED fused block (bn1/bn2 folded into operand loads, folded
+    bn3 backward, sign mask, shortcut BatchNorm applied while adding, shortcut gradient accumulated on top of conv1's)
+    is held to the real reference's outputs at 5e-5: forward, dx, every dW / dgamma / dbeta, running statistics, eval
+    mode.  models/resnet.py:78-98."""
+    from scat_amd import ops
+    from scat_amd.models import resnet as R
+    from scat_amd import nn as snn
+
+    g = golden("bottleneck")
+    saved = ops.get_math_mode()
+    ops.set_math_mode(math)
+    try:
+        ds = torch.nn.Sequential(snn.Conv2d(64, 256, 1, 1, bias=False), snn.BatchNorm2d(256))
+        blk = R.Bottleneck(64, 64, 1, ds)
+        full = synth.to_torch(synth.resnet_state(31, "", (1, 0, 0, 0)))
+        blk.load_state_dict({k[len("layer1.0."):]: v for k, v in full.items() if k.startswith("layer1.0.")}, strict=True)
+        blk.cuda().train()
+        x = T(synth.normal_like(32, "x", (4, 64, 8, 8))).cuda().requires_grad_(True)
+        cot = T(synth.normal_like(33, "cot", (4, 256, 8, 8))).cuda()
+        y = blk(x)
+        assert digest_err(digest(y), g["y_train_d"]) < 2e-5
+        assert rel_err(y.detach().cpu().numpy()[:, ::37], g["y_train"]) < 2e-5
+        cot0 = cot.clone()
+        (y * cot).sum().backward()
+        assert torch.equal(cot, cot0)                      # the caller's gradient tensor is not modified in place
+        assert digest_err(digest(x.grad), g["dx"]) < 5e-5
+        assert rel_err(x.grad[0, :2], g["dx_head"]) < 5e-5
+        for k, p in blk.named_parameters():
+            assert digest_err(digest(p.grad), g["g:" + k]) < 5e-5, k
+        for k, b in blk.named_buffers():
+            assert rel_err(b.double(), g["buf:" + k]) < 5e-6, k
+        blk.eval()
+        with torch.no_grad():
+            assert digest_err(digest(blk(x)), g["y_eval_d"]) < 2e-5
+    finally:
+        ops.set_math_mode(saved)
+
+
+def test_backbone_modules_standalone():
+    """Every attribute of the ResNet mirror is a working module on its own, as in the reference (models/resnet.py:
+    105-116, 142-162): the stem pieces, a whole nn.Sequential layer of Bottlenecks, AvgPool2d(7) — composed by hand
+    they give ResNet.forward's outputs (the fused node), forward and input gradient."""
+    from scat_amd.models import resnet as R
+
+    net = R.resnet50()
+    net.load_state_dict(synth.to_torch(synth.resnet_state(41, "")), strict=True)
+    net.cuda().eval()
+    x = T(synth.images(42, 2)).cuda()
+    with torch.no_grad():
+        feat, x1, x2, x3, x4 = net(x)
+        h = net.maxpool(net.relu(net.bn1(net.conv1(x))))
+        y1 = net.layer1(h)
+        y2 = net.layer2(y1)
+        y4 = net.layer4(net.layer3(y2))
+        f = net.relu(net.fc1(net.relu(net.avgpool(y4).view(2, -1))))
+    assert rel_err(y1, x1) < 1e-5 and rel_err(y2, x2) < 1e-5 and rel_err(y4, x4) < 1e-5 and rel_err(f, feat) < 1e-5
+    # train mode, one layer: gradients through the per-block nodes == through the fused node's executor
+    net.train()
+    a = x1.detach().clone().requires_grad_(True)
+    cot = T(synth.normal_like(43, "cot", tuple(x2.shape))).cuda()
+    ya = net.layer2(a)
+    (ya * cot).sum().backward()
+    ga = {k: p.grad.clone() for k, p in net.layer2.named_parameters()}
+    ref = torch.nn.functional.max_pool2d
+    mp = ref(torch.relu(x1), 3, 2, 1)
+    assert rel_err(net.maxpool(torch.relu(x1)), mp) == 0.0
+    assert all(torch.isfinite(v).all() for v in ga.values()) and torch.isfinite(a.grad).all()
+    with pytest.raises(RuntimeError):
+        net.avgpool(x3)                                    # AvgPool2d(7) needs the 7x7 map, like the reference's fc1
+
+
 def test_encoder_performer_config5():
     """BASELINE config 5 wiring (ResNet-50 tokens -> FAVOR+ blocks -> per-token offsets -> iterative regressor):
     the token path must be exactly performer_attn_block (golden-tested above) applied to EncoderTransformer's

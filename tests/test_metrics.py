@@ -76,3 +76,32 @@ def test_warmup_schedule_and_pretrained_ingest(tmp_path):
     missing, unexpected = load_pretrained_backbone(bb, str(f))
     assert set(unexpected) == {"fc.weight", "fc.bias"} and {"fc1.weight", "fc1.bias"} <= set(missing)
     assert torch.equal(bb.conv1.weight.data, src["conv1.weight"]) and torch.equal(bb.bn1.weight.data, src["bn1.weight"])
+
+
+def test_pretrained_flag_is_honoured_or_loud(tmp_path, monkeypatch):
+    """models/resnet.py:192-195 loads ImageNet weights when pretrained=True.  The mirror takes them from a local file
+    (SCAT_RESNET50_CKPT / SCAT_PRETRAINED_DIR / torch hub cache) and must WARN when there is none instead of silently
+    training the backbone from its random initialisation."""
+    import warnings
+
+    from scat_amd.models import resnet
+
+    monkeypatch.delenv("SCAT_RESNET50_CKPT", raising=False)
+    monkeypatch.delenv("SCAT_PRETRAINED_DIR", raising=False)
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "nohub"))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        resnet.resnet50(pretrained=True)
+    assert any("RANDOM initialisation" in str(x.message) for x in w)
+    f = tmp_path / "resnet50.pth"
+    torch.save({"conv1.weight": torch.full((64, 3, 7, 7), 0.25), "bn1.running_var": torch.full((64,), 3.0),
+                "fc.weight": torch.zeros(1000, 2048)}, f)
+    monkeypatch.setenv("SCAT_RESNET50_CKPT", str(f))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        net = resnet.resnet50(pretrained=True)
+    assert not any("RANDOM" in str(x.message) for x in w)
+    assert torch.all(net.conv1.weight == 0.25) and torch.all(net.bn1.running_var == 3.0)
+    monkeypatch.delenv("SCAT_RESNET50_CKPT")
+    monkeypatch.setenv("SCAT_PRETRAINED_DIR", str(tmp_path))
+    assert resnet.pretrained_checkpoint("resnet50") == str(f)
