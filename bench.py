@@ -1,22 +1,27 @@
 #!/usr/bin/env python
 """Headline benchmark: images/sec of one full reg_transformer train step (train.py:136-209 of the
-reference: forward, loss, backward, [gradient all-reduce], Adam) on MI355X.
+reference: [input pipeline,] forward, loss, backward, [gradient all-reduce], Adam) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config resnet50|hrnet_w32|performer]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1]: ResNet-50 backbone + dim-halving transformer (8 heads) +
-3 regressor iterations, pl_reg, mask_rate 0.2, positional encoding, batch 96 per GPU, synthetic
-256x256 RGB source images resampled to the network's only legal geometry 224x224
-BEFORE the timed region; fp32 end to end.  One JSON line on rank 0.
+Default workload = BASELINE.json configs[1]: ResNet-50 backbone + dim-halving transformer (8 heads) +
+3 regressor iterations, pl_reg, mask_rate 0.2, positional encoding, batch 96 per GPU; fp32 end to end.
+A step starts from the synthetic 256x256 uint8 source batch resident in HBM: normalise + bilinear resample to the
+network's only legal geometry 224x224 (dataset/load_STB.py:48-67) runs INSIDE the timed step.
+``value`` = images / wall time of the K steps between the two barriers; the median of the per-step HIP-event
+times is reported beside it.  ``--config hrnet_w32`` / ``performer`` time BASELINE configs[3] / configs[4] on the same
+contract.  One JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import random
+import statistics
 import sys
 import time
 from types import SimpleNamespace
@@ -28,57 +33,126 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # fp32 work per image of one train step (SURVEY §8d / BASELINE.md §2, torch flop counter on the reference)
-GF_TRAIN_PER_IMG = 24.987
+GF_TRAIN_PER_IMG = {"resnet50": 24.987, "hrnet_w32": 3 * (15.63 + 0.527), "performer": 3 * (8.179 + 0.017 + 3 * 0.240)}
 PEAK_F32_MFMA_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_BF16_MFMA_TF = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16, 32 clk)
-PEAK_HBM_GBS = 8000.0
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured with a float4 copy)
 
 
-def build_inputs(batch, seed, device, src=256):
-    """Synthetic uint8 source images -> [-1,1] -> bilinear 224x224 (dataset/load_STB.py:55 Resize(224))."""
+def opt_ns(**kw):
+    d = dict(vit_heads=8, pl_reg=True, iteration=3, pos_embed=True, mask_rate=0.2, vit_depth=3, hrnet_width=32)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def make_net(config, seed, device):
+    """Random-init weights of the named architecture from the in-repo counter hash (identical on every rank)."""
     from scat_amd import synth
+    from scat_amd.models import hand_net as H
 
-    from scat_amd import ops
-
-    u8 = torch.from_numpy(synth.randint_u8(seed, "bench_images", (batch, 3, src, src))).to(device)
-    x = ops.preprocess_u8(u8, (224, 224))      # normalise + bilinear resize in one HIP kernel
-    lab = torch.from_numpy(synth.labels(seed + 1, batch)).to(device)
-    return x.contiguous(), lab
-
-
-def make_net(seed, device):
-    from scat_amd import synth
-    from scat_amd.models.hand_net import EncoderTransformer
-
-    opt = SimpleNamespace(vit_heads=8, pl_reg=True, iteration=3, pos_embed=True, mask_rate=0.2, vit_depth=3)
-    net = EncoderTransformer(opt, torch.from_numpy(synth.mean_params(seed)))
-    net.load_state_dict(synth.to_torch(synth.encoder_transformer_state(seed, 8)), strict=True)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    if config == "resnet50":
+        net = H.EncoderTransformer(opt_ns(), T(synth.mean_params(seed)))
+        net.load_state_dict(synth.to_torch(synth.encoder_transformer_state(seed, 8)), strict=True)
+    elif config == "hrnet_w32":
+        # BASELINE configs[3]: HRNet(c=32, nof_joints=128) -> view(512,28,28) -> conv3x3/2 -> [B,128,196] ->
+        # vit.Transformer(196,3,8,64,392) -> 3 x Linear(257->61)   (hand_net.py:150-213 with models.vit swapped in)
+        net = H.EncoderTransformerHRNet(opt_ns(pl_reg=False), T(synth.mean_params(seed, 61)))
+        net.load_state_dict(synth.to_torch(synth.hrnet_wrapper_state(seed + 1, net.state_dict())), strict=True)
+    else:
+        # BASELINE configs[4]: ResNet-50 tokens -> 3 x performer_attn_block(49, 16) -> iteration 5, mask 0.2
+        torch.manual_seed(seed)
+        net = H.EncoderPerformer(opt_ns(vit_heads=16, iteration=5, pl_reg=False), T(synth.mean_params(seed)))
+        sd = synth.to_torch(synth.encoder_transformer_state(seed, 8))
+        net.main_encoder.load_state_dict({k[len("main_encoder."):]: v for k, v in sd.items()
+                                          if k.startswith("main_encoder.")}, strict=True)
     return net.to(device).train()
 
 
-def cpu_baseline(batch=32, steps=5):
+class Step:
+    """One train.py inner iteration starting from the uint8 source batch in HBM."""
+
+    def __init__(self, config, net, dev):
+        from scat_amd import ops
+        from scat_amd.trainer import TrainStep
+
+        self.ops, self.config = ops, config
+        if config == "hrnet_w32":
+            # the reference has no trainer for this wrapper (train.py builds EncoderTransformer only, train.py:49-57)
+            # and its 61 outputs are MANO parameters, not joints: the step is forward + a fixed linear functional of
+            # the outputs + backward + torch.optim.Adam (unattended data parallelism attaches itself in forward)
+            self.net = net
+            self.opt = torch.optim.Adam(net.parameters(), lr=1e-5)
+            self.cot = None
+            self.ts = None
+        else:
+            self.ts = TrainStep(net, lr=5e-4)
+
+    def __call__(self, u8, lab):
+        x = self.ops.preprocess_u8(u8, (224, 224))      # normalise + bilinear resize, one HIP kernel, in the step
+        if self.ts is not None:
+            return self.ts(x, lab)
+        self.opt.zero_grad(set_to_none=True)
+        pred = self.net(x)
+        pred = pred[0] if isinstance(pred, tuple) else pred
+        if self.cot is None:
+            self.cot = torch.full_like(pred, 1e-3)
+        loss = (pred * self.cot).sum()
+        loss.backward()
+        self.opt.step()
+        return loss.detach(), None, None, pred.detach()
+
+
+def build_inputs(batch, seed, device, src=256):
+    from scat_amd import synth
+
+    u8 = torch.from_numpy(synth.randint_u8(seed, "bench_images", (batch, 3, src, src))).to(device)
+    lab = torch.from_numpy(synth.labels(seed + 1, batch)).to(device)
+    return u8, lab
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline():
     """The CPU oracle (a torch-CPU restatement of the reference path, pinned to the reference's outputs by
-    tests/golden) on a bounded sample of the same workload, all host cores."""
+    tests/golden) on a bounded sample of the same workload: batch 96 and batch 8, every core the
+    box gives this process."""
     from oracle import scat_oracle as O
     from scat_amd import synth
 
-    # the box's CPU share, not the host's core count: oversubscribed OpenMP threads spin
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("SCAT_CPU_THREADS", "16")))
+    cores = len(os.sched_getaffinity(0))
+    if os.environ.get("SCAT_CPU_THREADS"):
+        cores = min(cores, int(os.environ["SCAT_CPU_THREADS"]))
     torch.set_num_threads(cores)
     sd = synth.to_torch(synth.encoder_transformer_state(1, 8))
     mp = torch.from_numpy(synth.mean_params(1))
-    x = torch.from_numpy(synth.images(2, batch))
-    lab = torch.from_numpy(synth.labels(3, batch))
-    st = {}
-    random.seed(3)
-    O.train_step(sd, mp, x, lab, st, 1)      # warm-up
-    t0 = time.perf_counter()
-    for s in range(steps):
-        O.train_step(sd, mp, x, lab, st, s + 2)
-    dt = time.perf_counter() - t0
-    return {"value": round(batch * steps / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} train steps at batch {batch} (224x224, heads 8, iteration 3, pl_reg), "
-                      f"{dt:.1f} s of CPU work, torch {torch.__version__} CPU"}
+    res = {}
+    for batch, warm, steps in ((8, 2, 5), (96, 1, 2)):
+        x = torch.from_numpy(synth.images(2, batch))
+        lab = torch.from_numpy(synth.labels(3, batch))
+        st = {}
+        random.seed(3)
+        for s in range(warm):
+            O.train_step(sd, mp, x, lab, st, s + 1)
+        ts = []
+        for s in range(steps):
+            t0 = time.perf_counter()
+            O.train_step(sd, mp, x, lab, st, warm + s + 1)
+            ts.append(time.perf_counter() - t0)
+        res[batch] = (batch / statistics.median(ts), sum(ts), steps)
+    return {"value": round(res[96][0], 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "batch8_images_per_s": round(res[8][0], 2),
+            "sample": f"median of {res[96][2]} train steps at batch 96 after 1 warm-up ({res[96][1]:.1f} s) and of "
+                      f"{res[8][2]} steps at batch 8 after 2 ({res[8][1]:.1f} s): 224x224, heads 8, iteration 3, "
+                      f"pl_reg, Adam; torch {torch.__version__} CPU, {cores} threads"}
 
 
 def instantiation_of(label):
@@ -86,6 +160,9 @@ def instantiation_of(label):
     import re
     tf = "t" if label.endswith("_tf") or "_tf_" in label else "f"
     ds = "t" if "_bnb" in label else "f"      # dual-source operand (folded BatchNorm backward)
+    m = re.search(r"_split_pc(\d+)x128x32", label)
+    if m:
+        return f"conv1x1_pc_kernel<{int(m.group(1)) // 128},{tf},0>"
     m = re.search(r"_split_(\d+)x(\d+)x32", label)
     if m:       # pointwise / taps kernel: WM = rows / 32
         return f"conv1x1_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf},{ds}>"
@@ -99,69 +176,96 @@ def instantiation_of(label):
     return label
 
 
-def dominant_kernel_roofline(ts, x, lab):
-    """One extra instrumented step (outside the timed region): HIP events around every launch of the
-    contraction engine, grouped by kernel instantiation; report the one with the most total time."""
+def latest_traffic():
+    """HBM bytes per launch from the newest committed rocprofv3 --pmc passes over this bench (tools/traffic_json.py)"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return {}, None
+    try:
+        return json.load(open(files[-1])), os.path.basename(files[-1])
+    except (OSError, ValueError):
+        return {}, None
+
+
+def kernel_rooflines(step, u8, lab):
+    """One extra instrumented step (outside the timed region): HIP events on the launch stream around every launch of
+    the contraction kernels (algorithmic FLOPs) and of the BatchNorm passes (algorithmic bytes), grouped by kernel;
+    report the contraction kernel and the BatchNorm pass with the most total time."""
     from scat_amd import ops
+    from scat_amd.models import hand_net as hand_net_mod
     from scat_amd.models import resnet as resnet_mod
 
     # per-kernel durations are only meaningful when kernels do not share the GPU: this one step runs the
     # weight gradients on the main stream instead of the side stream (the timed steps overlap them)
-    from scat_amd.models import hand_net as hand_net_mod
-
     side, resnet_mod.SIDE_WGRAD = resnet_mod.SIDE_WGRAD, False
     overlap, hand_net_mod.OVERLAP_TOKENS = hand_net_mod.OVERLAP_TOKENS, False     # (and the token path in line)
-    ops.PROFILE = []
-    ts(x, lab)
+    ops.PROFILE, ops.PROFILE_HBM = [], []
+    step(u8, lab)
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
+    rec_hbm, ops.PROFILE_HBM = ops.PROFILE_HBM, None
     resnet_mod.SIDE_WGRAD = side
     hand_net_mod.OVERLAP_TOKENS = overlap
-    agg = {}
-    for name, flops, e0, e1 in rec:
-        ms = e0.elapsed_time(e1)
-        a = agg.setdefault(name, [0.0, 0.0, 0])
-        a[0] += ms
-        a[1] += flops
-        a[2] += 1
-    if not agg:
-        return None, {}
-    name, (ms, flops, n) = max(agg.items(), key=lambda kv: kv[1][0])
-    tf = flops / (ms * 1e-3) / 1e12
-    table = {k: {"launches": v[2], "ms": round(v[0], 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2)}
-             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
-    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
-    # collected separately, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); null if this kernel was not profiled
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-            traffic = json.load(fh).get(instantiation_of(name), {}).get("hbm_bytes_per_launch")
-    except OSError:
-        pass
-    # kernels whose label says "split" form each fp32 product from six bf16 MFMA terms (DESIGN.md §3.0): their
-    # ceiling for ALGORITHMIC fp32 FLOPs is the dense bf16 MFMA peak / 6; the others use the fp32 MFMA
-    split = "_split" in name
-    peak = round(PEAK_BF16_MFMA_TF / 6.0, 1) if split else PEAK_F32_MFMA_TF
-    roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(tf / peak, 4), "traffic": traffic, "kernel": name, "launches_per_step": n,
-            "peak_basis": ("2500 TF dense bf16 MFMA / 6 bf16 terms per fp32 product" if split
-                           else "157.3 TF fp32 MFMA"),
-            "frac_of_fp32_mfma_peak": round(tf / PEAK_F32_MFMA_TF, 4),
-            "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3)}
-    return roof, table
+
+    def aggregate(records):
+        agg = {}
+        for name, work, e0, e1 in records:
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += work
+            a[2] += 1
+        return agg
+
+    agg = aggregate(rec)
+    roof, table = None, {}
+    if agg:
+        name, (ms, flops, n) = max(agg.items(), key=lambda kv: kv[1][0])
+        tf = flops / (ms * 1e-3) / 1e12
+        table = {k: {"launches": v[2], "ms": round(v[0], 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2)}
+                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
+        # collected separately, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); null if this kernel was not profiled
+        tj, tj_file = latest_traffic()
+        traffic = tj.get(instantiation_of(name), {}).get("hbm_bytes_per_launch")
+        # kernels whose label says "split" form each fp32 product from six bf16 MFMA terms (DESIGN.md §3.0): their
+        # ceiling for ALGORITHMIC fp32 FLOPs is the dense bf16 MFMA peak / 6; the others use the fp32 MFMA
+        split = "_split" in name
+        peak = round(PEAK_BF16_MFMA_TF / 6.0, 1) if split else PEAK_F32_MFMA_TF
+        roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(tf / peak, 4), "traffic": traffic, "traffic_source": tj_file, "kernel": name,
+                "launches_per_step": n,
+                "peak_basis": ("2500 TF dense bf16 MFMA / 6 bf16 terms per fp32 product" if split
+                               else "157.3 TF fp32 MFMA"),
+                "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3)}
+    roof_hbm = None
+    agg = aggregate(rec_hbm)
+    if agg:
+        name, (ms, nbytes, n) = max(agg.items(), key=lambda kv: kv[1][0])
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        roof_hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "kernel": name, "launches_per_step": n,
+                    "avg_launch_ms": round(ms / n, 4), "algorithmic_mb_per_launch": round(nbytes / n / 1e6, 2),
+                    "all_passes": {k: {"launches": v[2], "ms": round(v[0], 3),
+                                       "gb_per_s": round(v[1] / (v[0] * 1e-3) / 1e9, 1)}
+                                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+    return roof, roof_hbm, table
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=96, help="per-GPU batch (reference: 96, script/ablation_pose.sh:11)")
+    ap.add_argument("--config", default="resnet50", choices=sorted(GF_TRAIN_PER_IMG),
+                    help="resnet50 = BASELINE configs[1]/[2] (the headline); hrnet_w32 = configs[3]; performer = configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
     a = ap.parse_args()
 
+    # distributed first: RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run, the device is chosen and the
+    # process group created before anything touches the GPU
     from scat_amd.dp import init_distributed
 
     rank, local, world = init_distributed()
@@ -169,13 +273,12 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     import torch.distributed as dist
     from scat_amd._lib import lib
-    from scat_amd.trainer import TrainStep
 
     lib().scat_check_device()
     dev = torch.device("cuda", local)
-    net = make_net(1, dev)                      # identical weights on every rank
-    ts = TrainStep(net, lr=5e-4)
-    x, lab = build_inputs(a.batch, 100 + rank, dev)   # each rank its own shard (weak scaling)
+    net = make_net(a.config, 1, dev)            # identical weights on every rank
+    step = Step(a.config, net, dev)
+    u8, lab = build_inputs(a.batch, 100 + rank, dev)   # each rank its own shard (weak scaling)
     random.seed(3 + rank)
 
     def sync():
@@ -188,49 +291,64 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    note(f"model + data ready on {torch.cuda.get_device_name(dev)}; warm-up {a.warmup} steps")
+    note(f"{a.config}: model + data ready on {torch.cuda.get_device_name(dev)}; warm-up {a.warmup} steps")
     for _ in range(a.warmup):
-        ts(x, lab)
+        step(u8, lab)
     sync()
     note(f"timing {a.steps} steps")
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss, parts, lpl, pred = ts(x, lab)
+    for i in range(a.steps):
+        marks[i].record()
+        loss, parts, lpl, pred = step(u8, lab)
+    marks[a.steps].record()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    med = statistics.median(per_step)
     final_loss = float(loss.item())
-    note(f"{a.steps} steps in {dt:.3f} s = {a.batch * world * a.steps / dt:.1f} img/s; roofline + CPU baseline legs")
+    note(f"{a.steps} steps in {dt:.3f} s = {a.batch * world * a.steps / dt:.1f} img/s (median step {med:.3f} ms); "
+         "roofline + CPU baseline legs")
 
-    roof, table = (None, {})
+    roof, roof_hbm, table = None, None, {}
     if not a.no_roofline:
         # every rank runs the instrumented step (it contains the gradient all-reduces); rank 0 reports
-        roof, table = dominant_kernel_roofline(ts, x, lab)
+        roof, roof_hbm, table = kernel_rooflines(step, u8, lab)
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config == "resnet50":
         cpu = cpu_baseline()
 
     if rank == 0:
         imgs = a.batch * world * a.steps
-        step_tf = GF_TRAIN_PER_IMG * a.batch / (dt / a.steps) / 1e3
+        step_tf = GF_TRAIN_PER_IMG[a.config] * a.batch / (dt / a.steps) / 1e3
+        workloads = {
+            "resnet50": "ResNet-50 + dim-halving transformer (8 heads) + 3 regressor iterations, pl_reg, mask_rate 0.2, "
+                        "pos_embed, Adam; full train step (BASELINE configs[1])",
+            "hrnet_w32": "HRNet-W32 + vit.Transformer(196,3,8,64,392) + 3 x Linear(257->61), Adam; forward + linear "
+                         "functional + backward + update (BASELINE configs[3])",
+            "performer": "ResNet-50 tokens + 3 x performer_attn_block(49, heads 16) + 5 regressor iterations, mask_rate "
+                         "0.2, Adam; full train step (BASELINE configs[4])"}
         out = {
             "metric": "images/sec (train step, 256x256 source -> 224x224, reg_transformer)",
             "value": round(imgs / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ResNet-50 + dim-halving transformer (8 heads) + 3 regressor iterations, "
-                                   "pl_reg, mask_rate 0.2, pos_embed, Adam; full train step",
-                       "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": "3x224x224 fp32 "
-                       "(from 256x256 synthetic uint8, resized before the timed region)",
+            "config": {"workload": workloads[a.config],
+                       "batch_per_gpu": a.batch, "global_batch": a.batch * world,
+                       "input": "uint8 3x256x256 synthetic source batch resident in HBM; normalise + bilinear resize to "
+                                "3x224x224 fp32 inside the timed step",
                        "parallelism": f"dp{world}", "final_loss": final_loss,
+                       "median_ms_per_step": round(med, 3),
+                       "median_images_per_s": round(a.batch * world / (med * 1e-3), 2),
                        "products": ("fp32 operands as 3 bf16 terms, 6 bf16 MFMA terms per product, fp32 accumulate "
                                     "(error <= 2^-25 per product; DESIGN.md 3.0)" if lib().scat_get_math_mode() == 1
                                     else "fp32 MFMA"),
                        "whole_step_tflops_per_gpu": round(step_tf, 2)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_hbm": roof_hbm, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
         if a.kernel_table:

@@ -314,8 +314,114 @@ def g_coarse():
     np.savez(os.path.join(GOLD, "coarse.npz"), **out)
 
 
+def g_dp():
+    """G9: the data-parallel parity definition.  Two shards of 4 images go through the REAL reference
+    network independently from identical weights (train.py has no distributed code: this is what N independent
+    train.py processes would compute), the two gradient sets are averaged, Adam is applied once.  An N-replica run
+    must reproduce the averaged gradients and the updated weights.  Seeds as tests/test_gpu_dp.py uses them."""
+    shards = []
+    for r in range(2):
+        net, mp = _enc(seed=43)
+        net.train()
+        x = T(synth.images(700 + r, 4))
+        lab = T(synth.labels(710 + r, 4))
+        random.seed(11)
+        pred, fv, pl = net(x)
+        loss, l3, l2, lpl = O.scat_loss(pred, lab, pl)
+        loss.backward()
+        shards.append((net, loss.item(), pred.detach().numpy()))
+    out = {"loss": np.array([s[1] for s in shards]), "pred0": shards[0][2], "pred1": shards[1][2]}
+    net = shards[0][0]
+    full = ("regressor.weight", "regressor.bias", "mask_token", "conv1x1_channel_reduction.weight",
+            "transformer.layers.2.1.net.2.weight", "transformer.layers.0.0.fn.norm.weight")
+    for (k, p), (_, q) in zip(net.named_parameters(), shards[1][0].named_parameters()):
+        g = (p.grad + q.grad) / 2
+        out["g:" + k] = digest(g, 8)
+        out["gnorm:" + k] = np.array([g.norm().item(), p.grad.norm().item(), q.grad.norm().item()])
+        if k in full:
+            out["g_full:" + k] = g.numpy()
+        p.grad = g
+    for r in range(2):      # BatchNorm statistics stay per replica (no SyncBN; what DDP does)
+        out[f"bn1.running_mean:{r}"] = shards[r][0].main_encoder.bn1.running_mean.numpy().copy()
+    optim = torch.optim.Adam(net.parameters(), lr=1e-4)
+    optim.step()
+    for k in full + ("main_encoder.fc1.bias", "main_encoder.layer4.2.bn3.weight"):
+        w = dict(net.named_parameters())[k].detach()
+        out["w:" + k] = w.numpy().copy() if w.numel() <= 4096 else digest(w, 64)
+    np.savez(os.path.join(GOLD, "dp.npz"), **out)
+
+
+def _eval_py_functions(*names):
+    """eval.py cannot be imported (it needs torchvision, cv2 and modules the repository does not ship: eval.py:37-48),
+    but its metric functions are self-contained: take their definitions out of the file where it lies (ast -> compile
+    -> exec in a namespace that has torch and numpy) and run THEM.  Nothing is copied into this repository."""
+    import ast
+
+    path = os.path.join(REF, "eval.py")
+    tree = ast.parse(open(path).read(), path)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(body) == len(names), [n.name for n in body]
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def metric_inputs():
+    """(pred[B,21,3], gt[B,21,3]) of the metric goldens: a rotated, scaled, shifted, noisy copy of gt (metres)"""
+    B = 12
+    gt = synth.normal_like(901, "gt", (B, 21, 3), 0.05)
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], dtype=np.float32)
+    pred = (1.3 * gt @ R.T + 0.02 + synth.normal_like(902, "n", (B, 21, 3), 0.004)).astype(np.float32)
+    return pred, gt
+
+
+def g_metrics():
+    """G10+: the reference's own evaluation formulae on seeded joints — MPJPE (eval.py:753), Procrustes
+    alignment (eval.py:110-161, as applied at :953) and PA-MPJPE, PCK / AUC (eval.py:300-340 with the thresholds of
+    :708/:744), acceleration error (data_utils/eval_utils.py:23-48, imported)."""
+    from data_utils.eval_utils import compute_accel, compute_error_accel
+
+    pa, cal_pck, area = _eval_py_functions("batch_compute_similarity_transform_torch", "cal_PCK", "_area_under_curve")
+    pred, gt = metric_inputs()
+    tp, tg = T(pred), T(gt)
+    out = {"mpjpe_per_sample": torch.sqrt(((tp - tg) ** 2).sum(dim=-1)).mean(dim=-1).numpy()}       # eval.py:753
+    out["mpjpe_mm"] = np.array(1000 * out["mpjpe_per_sample"].mean())                                 # eval.py:1050
+    aligned = pa(tp, tg)
+    out["pa_aligned"] = aligned.numpy()
+    out["pa_mpjpe_mm"] = np.array(1000 * torch.sqrt(((aligned - tg) ** 2).sum(dim=-1)).mean(dim=-1).numpy().mean())
+    rnge = np.arange(20, 51, 1.0)
+    pck = cal_pck(tp, tg, rnge)
+    out["rnge"] = rnge
+    out["pck"] = pck[:, -1]
+    out["auc"] = np.array(area(rnge / rnge.max(), pck[:, -1]))
+    out["pck_pa"] = cal_pck(aligned, tg, rnge)[:, -1]
+    out["accel_err"] = compute_error_accel(joints_gt=gt, joints_pred=pred)
+    out["accel"] = compute_accel(pred)
+    np.savez(os.path.join(GOLD, "metrics.npz"), **out)
+
+
+def g_ckpt():
+    """f4: the on-disk format.  The reference's own EncoderTransformer, loaded with the synthesised
+    weights, is saved with torch.save(net.state_dict()) exactly as train.py:237-246 does and read back; the golden
+    keeps the checkpoint's key order, shapes and a 4-number digest per tensor (not the 118 MB of values)."""
+    import tempfile
+
+    net, mp = _enc()
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "ref.pth")
+        torch.save(net.state_dict(), f)
+        sd = torch.load(f, map_location="cpu")
+    keys = list(sd.keys())
+    shapes = np.full((len(keys), 4), -1, dtype=np.int64)
+    for i, k in enumerate(keys):
+        shapes[i, :sd[k].dim()] = list(sd[k].shape)
+    np.savez(os.path.join(GOLD, "ckpt_keys.npz"), keys=np.array(keys), shapes=shapes,
+             digests=np.stack([digest(sd[k].float(), 4)[:4] for k in keys]))
+
+
 ALL = {"coarse": g_coarse, "hrnet": g_hrnet, "vt": g_vt, "bottleneck": g_bottleneck, "resnet": g_resnet, "encoder": g_encoder,
-       "trainstep": g_trainstep, "vit": g_vit, "performer": g_performer}
+       "trainstep": g_trainstep, "vit": g_vit, "performer": g_performer, "dp": g_dp, "metrics": g_metrics, "ckpt": g_ckpt}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

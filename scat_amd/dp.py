@@ -29,7 +29,8 @@ import torch.distributed as dist
 # SCAT_DP_CHECK=1: stream-ordering self-check.  zero_grad() poisons the flat gradient buffer with NaN; every bucket is
 # tested for NaN ON THE STREAM ITS COLLECTIVE IS ORDERED AFTER, immediately in front of the collective; finish() raises
 # if a bucket went out with a slice nobody had written yet (a producing stream that was not joined).
-DP_CHECK = os.environ.get("SCAT_DP_CHECK", "0") != "0"
+def _dp_check():
+    return os.environ.get("SCAT_DP_CHECK", "0") != "0"
 
 _PRODUCERS: List = []   # streams other than the caller's on which gradient kernels run (process-wide)
 
@@ -95,7 +96,7 @@ class GradBuckets:
         self._comm_stream = None   # the stream every collective is ordered after (device runs only)
         self._checks = []
         self._host_stage = {}
-        self.check = DP_CHECK
+        self.check = _dp_check()
         self._avg_ok = False
         if self.world > 1:
             self._sync_replicas(model)

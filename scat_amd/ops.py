@@ -31,6 +31,21 @@ def _prof(flops, fn, *args):
     return r
 
 
+# the same for the HBM-bound BatchNorm passes: (entry point, algorithmic bytes, start event, end event)
+PROFILE_HBM = None
+
+
+def _prof_hbm(name, nbytes, fn, *args):
+    if PROFILE_HBM is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn(*args)
+    e1.record()
+    PROFILE_HBM.append((name, float(nbytes), e0, e1))
+    return r
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -383,8 +398,10 @@ def bn_train_stats(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=
     B, C, H, W = x.shape
     o = torch.empty((4, C), dtype=torch.float32, device=x.device)
     ws = workspace(lib().scat_bn_ws(B, C, H * W), x.device)
-    lib().scat_bn_train_stats(_p(x), B, C, H * W, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum,
-                              eps, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(ws), ws.numel(), _stream())
+    # algorithmic traffic: one read of x
+    _prof_hbm("bn_train_stats", 4.0 * x.numel(), lib().scat_bn_train_stats, _p(x), B, C, H * W, _p(gamma), _p(beta),
+              _p(running_mean), _p(running_var), momentum, eps, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(ws),
+              ws.numel(), _stream())
     return o[0], o[1], o[2], o[3]
 
 
@@ -406,8 +423,10 @@ def bn_apply(x, scale, shift, residual=None, relu=False, out=None, want_mask=Fal
     mask = None
     if want_mask and (H * W) % 4 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in (x, y, residual)):
         mask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=x.device)
-    lib().scat_bn_apply(_p(x), _p(scale), _p(shift), _p(residual), _p(res_scale), _p(res_shift), int(relu), _p(y),
-                        _p(mask), B, C, H * W, _stream())
+    # algorithmic traffic: read x (+ residual), write y (+ 1 bit per element of mask)
+    nb = x.numel() * (8.0 + (4.0 if residual is not None else 0.0) + (0.25 if mask is not None else 0.0))
+    _prof_hbm("bn_apply" + ("_res" if residual is not None else ""), nb, lib().scat_bn_apply, _p(x), _p(scale), _p(shift),
+              _p(residual), _p(res_scale), _p(res_shift), int(relu), _p(y), _p(mask), B, C, H * W, _stream())
     return (y, mask) if want_mask else y
 
 
@@ -423,9 +442,13 @@ def bn_bwd(dy, x, y_out, relu, scale, shift, save_mean, save_invstd, gamma, dgam
     dgamma = dgamma if dgamma is not None else torch.empty_like(gamma)
     dbeta = dbeta if dbeta is not None else torch.empty_like(gamma)
     ws = workspace(lib().scat_bn_ws(B, C, H * W), x.device)
-    lib().scat_bn_bwd(_p(dy), _p(x), _p(y_out), _p(y_mask), int(relu), _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
-                      _p(gamma), _p(dgamma), _p(dbeta), _p(dx), _p(dres), int(dres_accumulate), B, C, H * W, _p(ws),
-                      ws.numel(), _stream())
+    # algorithmic traffic of the two passes (reduce: dy, x; apply: dy, x -> dx [, masked gradient]); the block-output
+    # sign comes from y_out (4 B) or its mask (1 bit) in both passes
+    sign = 8.0 if y_out is not None else (0.0625 if y_mask is not None else 0.0)
+    nb = x.numel() * (8.0 + 12.0 + sign + (4.0 if dres is not None and dres is not dy else 0.0))
+    _prof_hbm("bn_bwd" + ("_res" if dres is not None else ""), nb, lib().scat_bn_bwd, _p(dy), _p(x), _p(y_out),
+              _p(y_mask), int(relu), _p(scale), _p(shift), _p(save_mean), _p(save_invstd), _p(gamma), _p(dgamma),
+              _p(dbeta), _p(dx), _p(dres), int(dres_accumulate), B, C, H * W, _p(ws), ws.numel(), _stream())
     return dx, dgamma, dbeta
 
 
@@ -440,9 +463,12 @@ def bn_bwd_pre(dy, x, relu, scale, shift, save_mean, save_invstd, gamma, dgamma=
     dbeta = dbeta if dbeta is not None else torch.empty_like(gamma)
     coef3 = torch.empty((3, C), dtype=torch.float32, device=x.device)
     ws = workspace(lib().scat_bn_ws(B, C, H * W), x.device)
-    lib().scat_bn_bwd_pre(_p(dy), _p(dy_add), _p(x), _p(y_out), _p(y_mask), int(relu), _p(scale), _p(shift), _p(save_mean),
-                          _p(save_invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(coef3), B, C, H * W, _p(ws), ws.numel(),
-                          _stream())
+    # algorithmic traffic: read dy (+ dy_add), x, the sign; write the masked gradient
+    sign = 4.0 if y_out is not None else (0.03125 if y_mask is not None else 0.0)
+    nb = x.numel() * (12.0 + sign + (4.0 if dy_add is not None else 0.0))
+    _prof_hbm("bn_bwd_pre", nb, lib().scat_bn_bwd_pre, _p(dy), _p(dy_add), _p(x), _p(y_out), _p(y_mask), int(relu),
+              _p(scale), _p(shift), _p(save_mean), _p(save_invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(coef3), B, C,
+              H * W, _p(ws), ws.numel(), _stream())
     return coef3, dgamma, dbeta
 
 

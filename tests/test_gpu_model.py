@@ -470,9 +470,14 @@ def test_backbone_modules_standalone():
 
 def test_encoder_performer_config5():
     """BASELINE config 5 wiring (ResNet-50 tokens -> FAVOR+ blocks -> per-token offsets -> iterative regressor):
-    the token path must be exactly performer_attn_block (golden-tested above) applied to EncoderTransformer's
-    tokens, checked here against a torch fp64 evaluation of the head on the same tokens, and every trainable
-    parameter must receive a finite gradient."""
+    the token path must be exactly performer_attn_block (golden-tested above against the reference's class) applied
+    to EncoderTransformer's tokens.  Checked against a torch fp64 evaluation of the whole head on the device's own
+    backbone outputs — tokens (1x1 reduction, +PE, mask-token scatter), three oracle performer blocks
+    (models/vision_performer.py:34-68), the per-token Linear, the iteration-5 regressor loop and the root-relative
+    shift (hand_net.py:379-393) — at 1e-4 on the 21-joint offsets; every trainable parameter must receive a finite
+    gradient, and the head's gradients must match fp64 autograd of the same evaluation."""
+    import torch.nn.functional as F
+
     from scat_amd.models.hand_net import EncoderPerformer
 
     torch.manual_seed(3)
@@ -482,14 +487,60 @@ def test_encoder_performer_config5():
     pred, feat_visual = net(x)
     assert pred.shape == (2, 66) and feat_visual.shape == (2, 21, 28, 28)
     assert torch.isfinite(pred).all() and (pred[:, 6:9] == 0).all()          # root-relative: joint 1 is the origin
+
+    def head_fp64(sd, main_feat, x2, midx):
+        """the head in float64 from the backbone's outputs (differentiable w.r.t. sd's tensors)"""
+        fv = F.conv2d(x2, sd["conv1x1_channel_reduction.weight"])
+        tok = fv.view(2, 21, -1) + sd["positionalEncoding.pe"][0]
+        tok = tok.clone()
+        tok[:, midx, :] = sd["mask_token"][0, 0]
+        for l in range(3):
+            tok = O.performer_block(sd, tok, f"blocks.{l}.", 49, 16)
+        off = F.linear(tok, sd["to_offsets.weight"], sd["to_offsets.bias"]).reshape(2, -1)
+        p = T(synth.mean_params(3)).double().repeat(2, 1)
+        p = torch.cat([p[:, :3], p[:, 3:] + off], dim=1)
+        for _ in range(5):
+            p = p + F.linear(torch.cat([main_feat, p], dim=1), sd["regressor.weight"], sd["regressor.bias"])
+        j = p[:, 3:].view(2, 21, 3)
+        return torch.cat([p[:, :3], (j - j[:, 1:2]).reshape(2, -1)], dim=1), fv
+
+    with torch.no_grad():
+        main_feat, _, x2, _, _ = net.main_encoder(x)
+    random.seed(11)
+    midx = O.mask_indices(0.2)
+    sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
+    ref, fv = head_fp64(sd, main_feat.double().cpu(), x2.double().cpu(), midx)
+    assert rel_err(feat_visual, fv) < 2e-5
+    assert rel_err(pred[:, 3:66], ref[:, 3:66]) < 1e-4, rel_err(pred[:, 3:66], ref[:, 3:66])
+    assert rel_err(pred[:, :3], ref[:, :3]) < 1e-4
+
     net.train()
+    for m in net.modules():                       # dropout off (vision_performer.py:18,28 are active in train mode):
+        if m.__class__.__name__ == "Dropout":     # the comparison below wants the same function on both sides
+            m.eval()
     random.seed(11)
     pred, _ = net(x)
-    (pred * T(synth.normal_like(161, "cot", (2, 66))).cuda()).sum().backward()
+    cot = T(synth.normal_like(161, "cot", (2, 66))).cuda()
+    (pred * cot).sum().backward()
     for n, p in net.named_parameters():
         if p.requires_grad:
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
     assert net.blocks[0].w.grad is None                                      # frozen random features
+    # head gradients against fp64 autograd of the same head on the (train-mode) backbone outputs
+    with torch.no_grad():
+        was = {n: b.clone() for n, b in net.main_encoder.named_buffers()}
+        main_feat, _, x2, _, _ = net.main_encoder(x)       # batch statistics again: same outputs as in the step above
+        for n, b in net.main_encoder.named_buffers():
+            b.copy_(was[n])
+    sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
+    names = [n for n, p in net.named_parameters() if p.requires_grad and not n.startswith("main_encoder.")]
+    for n in names:
+        sd[n].requires_grad_(True)
+    ref, _ = head_fp64(sd, main_feat.double().cpu(), x2.double().cpu(), midx)
+    (ref * cot.double().cpu()).sum().backward()
+    for n in names:
+        g = dict(net.named_parameters())[n].grad
+        assert rel_err(g, sd[n].grad) < 5e-4, (n, rel_err(g, sd[n].grad))
 
 
 def test_prepared_weights_follow_training():

@@ -105,3 +105,73 @@ def test_pretrained_flag_is_honoured_or_loud(tmp_path, monkeypatch):
     monkeypatch.delenv("SCAT_RESNET50_CKPT")
     monkeypatch.setenv("SCAT_PRETRAINED_DIR", str(tmp_path))
     assert resnet.pretrained_checkpoint("resnet50") == str(f)
+
+
+def metric_inputs():
+    """the seeded joints of tests/golden/metrics.npz (oracle/gen_golden.py::metric_inputs)"""
+    B = 12
+    gt = synth.normal_like(901, "gt", (B, 21, 3), 0.05)
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], dtype=np.float32)
+    pred = (1.3 * gt @ R.T + 0.02 + synth.normal_like(902, "n", (B, 21, 3), 0.004)).astype(np.float32)
+    return pred, gt
+
+
+def check_metrics_against_reference(golden, device):
+    """scat_amd.metrics on ``device`` tensors against the outputs of the REFERENCE's own functions (eval.py:110-161,
+    300-340, 753; data_utils/eval_utils.py:6-48) stored in tests/golden/metrics.npz by oracle/gen_golden.py."""
+    g = golden("metrics")
+    pred, gt = metric_inputs()
+    tp, tg = torch.from_numpy(pred).to(device), torch.from_numpy(gt).to(device)
+    rel = lambda a, b: float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / np.abs(b).max())
+    assert rel(M.mpjpe_mm(tp, tg).item(), g["mpjpe_mm"]) < 2e-6
+    assert rel(M.procrustes_align(tp, tg).cpu().numpy(), g["pa_aligned"]) < 2e-5
+    assert rel(M.pa_mpjpe_mm(tp, tg).item(), g["pa_mpjpe_mm"]) < 1e-4
+    pck = M.pck(tp, tg, g["rnge"]).cpu().numpy()
+    assert np.abs(pck - g["pck"]).max() < 1e-4
+    assert abs(M.auc(g["rnge"], pck) - float(g["auc"])) < 1e-4
+    assert np.abs(M.pck(M.procrustes_align(tp, tg), tg, g["rnge"]).cpu().numpy() - g["pck_pa"]).max() < 1e-4
+    assert rel(M.accel_error(tg, tp).cpu().numpy(), g["accel_err"]) < 2e-5
+    # 66-wide network outputs (3 camera + 63 joints) and 63-wide labels, as eval.py slices them
+    p66 = torch.cat([torch.zeros(12, 3, device=device), tp.reshape(12, 63)], 1)
+    assert rel(M.mpjpe_mm(p66, tg.reshape(12, 63)).item(), g["mpjpe_mm"]) < 2e-6
+
+
+def test_metrics_reference_golden(golden):
+    check_metrics_against_reference(golden, "cpu")
+
+
+def test_checkpoint_format_matches_reference(golden, tmp_path):
+    """The reference's checkpoint (torch.save(net.state_dict()), train.py:237-246) as captured from its own module in
+    tests/golden/ckpt_keys.npz: the mirror's state_dict has the same keys in the same order with the same shapes, and
+    loads a reference-style .pth strictly (eval.py:399-400) — on CPU tensors (construction needs no GPU)."""
+    from types import SimpleNamespace
+
+    from oracle.util import digest
+
+    ck = golden("ckpt_keys")
+    keys = [str(k) for k in ck["keys"]]
+    sd = synth.to_torch(synth.encoder_transformer_state(51, 8))
+    assert sorted(sd.keys()) == sorted(keys) and len(keys) == 356
+    ref_sd = {}
+    for k, shp, dg in zip(keys, ck["shapes"], ck["digests"]):
+        shape = tuple(int(v) for v in shp if v >= 0)
+        assert sd[k].numel() == int(np.prod(shape)), k      # (the synthesiser keeps num_batches_tracked as [1])
+        ref_sd[k] = sd[k].reshape(shape)                     # exactly the reference's checkpoint: order, shapes
+        assert np.allclose(digest(ref_sd[k].float(), 4)[:4], dg, rtol=1e-6, atol=1e-9), k
+    f = tmp_path / "ref.pth"
+    torch.save(ref_sd, f)
+    saved_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self          # the ctor places mean_params with .cuda() (hand_net.py:321)
+    try:
+        from scat_amd.models.hand_net import EncoderTransformer
+
+        opt = SimpleNamespace(vit_heads=8, pl_reg=True, iteration=3, pos_embed=True, mask_rate=0.2, vit_depth=3)
+        net = EncoderTransformer(opt, torch.from_numpy(synth.mean_params(51)))
+    finally:
+        torch.Tensor.cuda = saved_cuda
+    r = net.load_state_dict(torch.load(f, map_location="cpu"), strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    own = net.state_dict()
+    assert list(own.keys()) == keys
+    assert all(tuple(own[k].shape) == tuple(ref_sd[k].shape) for k in keys)

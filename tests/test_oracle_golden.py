@@ -114,6 +114,33 @@ def test_encoder_transformer(golden):
     assert rel_err(params["regressor.weight"].grad, g["g_full:regressor.weight"]) < 2e-5
 
 
+def test_dp_parity_definition(golden):
+    """G9: two shards through the network independently from identical weights, gradients averaged, one
+    Adam step — the reference's modules wrote tests/golden/dp.npz; the oracle must reproduce it (it is what
+    tests/test_gpu_dp.py holds the N-replica HIP run to)."""
+    g = golden("dp")
+    grads = []
+    for r in range(2):
+        sd = synth.to_torch(synth.encoder_transformer_state(43, 8))
+        params = O.trainable(sd)
+        for p in params.values():
+            p.requires_grad_(True)
+        x, lab = T(synth.images(700 + r, 4)), T(synth.labels(710 + r, 4))
+        random.seed(11)
+        pred, fv, pl = O.encoder_transformer_forward(sd, T(synth.mean_params(43)), x)
+        assert rel_err(pred, g[f"pred{r}"]) < 2e-6
+        loss = O.scat_loss(pred, lab, pl)[0]
+        assert abs(loss.item() - g["loss"][r]) / abs(g["loss"][r]) < 2e-6
+        loss.backward()
+        assert rel_err(sd["main_encoder.bn1.running_mean"], g[f"bn1.running_mean:{r}"]) < 2e-6
+        grads.append({k: p.grad for k, p in params.items()})
+    for k in grads[0]:
+        m = (grads[0][k] + grads[1][k]) / 2
+        assert digest_err(digest(m, 8), g["g:" + k]) < 5e-5, k
+        if "g_full:" + k in g:
+            assert rel_err(m, g["g_full:" + k]) < 5e-5, k
+
+
 def test_trainstep(golden):
     g = golden("trainstep")
     sd = synth.to_torch(synth.encoder_transformer_state(61, 8))
