@@ -476,7 +476,12 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
 // reads only, the VALU by two whose streams never wait for the matrix pipe.
 // DIAG (timing experiments only, results are wrong): 1 = no activation loads, 2 = no weight loads, 4 = no MFMAs,
 // 8 = no output stores, 16 = no split / LDS writes
-template <int MI, bool TF, int DIAG = 0>
+// W4 (pointwise stride-1 layers with HW % 4 == 0): column (b, c) of the tile is pixel 4c + b instead of 32b + c.  A
+// producer lane then owns FOUR CONSECUTIVE pixels of four channels — four 16-byte loads per stage instead of sixteen
+// 4-byte ones, LDS writes of 8 bytes that consecutive lanes place in consecutive slots — and a consumer lane's four
+// accumulator columns are four consecutive pixels of one row: the epilogue stores 16 bytes per instruction instead of
+// 4.  The MFMA does not care which pixel a column is; only the two ends of the kernel know.
+template <int MI, bool TF, int DIAG = 0, bool W4 = false>
 __global__ __launch_bounds__(512, (MI == 1 ? 4 : 2)) void conv1x1_pc_kernel(PwDesc d, OutDesc dc) {
     constexpr int BN = 128, BM = 128 * MI, NI = 4, PT = 256;
     constexpr int NIT = 4 * BN / PT;                  // k-octets per producer thread per 32-channel stage
@@ -494,6 +499,91 @@ __global__ __launch_bounds__(512, (MI == 1 ? 4 : 2)) void conv1x1_pc_kernel(PwDe
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 
+    if constexpr (W4) {
+      if (wave >= 4) {
+        // ------------------------------------------------------------ producer, wide form: wavefront = k-octet,
+        // lane = (pixel quad p, channel half h)
+        const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(d.src, d.nsrc);
+        const __amdgpu_buffer_rsrc_t rsrc_sc = make_rsrc(TF ? d.scale : d.src, TF ? d.C : 0);
+        const __amdgpu_buffer_rsrc_t rsrc_sh = make_rsrc(TF ? d.shift : d.src, TF ? d.C : 0);
+        const int g = wave - 4, p = lane >> 1, h = lane & 1;
+        const int chw4 = d.HW * 4;
+        int boff;                                      // byte offset of (image, channel 8g + 4h, first pixel of the quad)
+        {
+            const int j = j0 + 4 * p;
+            const bool bok = j < d.npix;
+            const uint32_t jj = bok ? (uint32_t)j : 0u;
+            const uint32_t n = d.dHW.div(jj);
+            boff = bok ? (int)((n * (uint32_t)d.C * (uint32_t)d.HW + (jj - n * (uint32_t)d.HW)) * 4u) +
+                             (8 * g + 4 * h) * chw4 : OOB;
+        }
+        u32x4 bst[2][4];                               // [register set][channel m] = 4 pixels
+        f32x4 tsc[2], tsh[2];
+        auto load_b = [&](int st, auto set_tag) {     // st >= nstage: zeros
+            constexpr int Q = decltype(set_tag)::value;
+            const int c0 = st * PW_KS;
+            const int vo = (c0 + 8 * g < d.C && st < nstage) ? boff : OOB;      // C % 16 == 0: whole octets
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if constexpr (DIAG & 1) bst[Q][m] = u32x4{(uint32_t)vo, 0x3f800000u, (uint32_t)m, 0x40000000u};
+                else bst[Q][m] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vo, (c0 + m) * chw4, 0);
+            }
+            if constexpr (TF) {
+                const int co = (c0 + 8 * g + 4 * h < d.C && st < nstage) ? (c0 + 8 * g + 4 * h) * 4 : OOB;
+                tsc[Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, co, 0, 0));
+                tsh[Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, co, 0, 0));
+            }
+        };
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        auto store_b = [&](int st, u32x4* dst, auto set_tag) {
+            constexpr int Q = decltype(set_tag)::value;
+            u32x2* base = (u32x2*)(dst + g * BN + p) + h;             // plane 0, position p (pixel 4p), half h
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float x[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float t = __uint_as_float(bst[Q][m][k]);
+                    if constexpr (TF) {
+                        t = fmaf(t, tsc[Q][m], tsh[Q][m]);          // (channels >= C: scale = shift = 0 -> 0)
+                        t = d.relu ? fmaxf(t, 0.f) : t;
+                    }
+                    x[m] = t;
+                }
+                if constexpr (DIAG & 16) {
+                    asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+                } else {
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    split3(x[0], x[1], h0, m0, l0);
+                    split3(x[2], x[3], h1, m1, l1);
+                    u32x2* q = base + (size_t)k * 32 * 2;              // position k*32 + p
+                    q[0] = u32x2{h0, h1};
+                    q[(size_t)4 * BN * 2] = u32x2{m0, m1};
+                    q[(size_t)8 * BN * 2] = u32x2{l0, l1};
+                }
+            }
+        };
+        load_b(0, S0{});
+        load_b(1, S1{});
+        store_b(0, B0, S0{});
+        load_b(2, S0{});
+        store_b(1, B0 + BUF, S1{});
+        __syncthreads();
+        int wb = 2;
+        auto iter = [&](int s, auto par_tag) {
+            constexpr int P = decltype(par_tag)::value;
+            load_b(s + 3, std::integral_constant<int, P ^ 1>{});
+            store_b(s + 2, B0 + wb * BUF, par_tag);
+            wb = wb == 2 ? 0 : wb + 1;
+            __syncthreads();
+        };
+        for (int s = 0; s < nstage; s += 2) {
+            iter(s, S0{});
+            if (s + 1 < nstage) iter(s + 1, S1{});
+        }
+        return;
+      }
+    } else
     if (wave >= 4) {
         // ------------------------------------------------------------ producer
         const int ptid = threadIdx.x - 256;
@@ -667,6 +757,30 @@ __global__ __launch_bounds__(512, (MI == 1 ? 4 : 2)) void conv1x1_pc_kernel(PwDe
     if constexpr (DIAG & 8) {
         if (d.variant != 0x7fffffff) return;          // (never true: keeps the accumulators live)
     }
+    if constexpr (W4) {
+        // lane (l31, lh): rows (reg & 3) + 8 (reg >> 2) + 4 lh of its 32-row block, pixels j0 + 4 l31 .. + 3 = the four
+        // accumulator tiles' column l31: one 16-byte store per row (NCHW, whole quads inside one image)
+        const __amdgpu_buffer_rsrc_t rc = make_rsrc(dc.p, dc.n);
+        const int j = j0 + 4 * l31;
+        const bool colok = j < d.npix;
+        const uint32_t jj = colok ? (uint32_t)j : 0u;
+        const uint32_t n = dc.dHW.div(jj);
+        const int coloff = (int)n * dc.C * dc.HW + (int)(jj - n * (uint32_t)dc.HW);
+        const bool biasi = dc.bias && dc.bias_mode == 1;
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + (wave * MI + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const bool ok = colok && i < d.M;
+                const int vo = ok ? (coloff + i * dc.HW) * 4 : OOB;
+                const float bi = biasi ? dc.bias[i < d.M ? i : 0] : 0.f;
+                f32x4 v = f32x4{acc[a][0][r] + bi, acc[a][1][r] + bi, acc[a][2][r] + bi, acc[a][3][r] + bi};
+                if (dc.accumulate) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, vo, 0, 0));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, vo, 0, 0);
+            }
+        return;
+    }
     store_tile<MI, NI, BM, BN, 4, 1>(acc, dc, d.M, d.npix, i0, j0, 0);
 }
 
@@ -749,18 +863,19 @@ static void launch_pw_split(const PwDesc& d, const OutDesc& dc, hipStream_t st) 
 }
 
 // SCAT_PC: 0 = every wavefront stages and multiplies (conv1x1_split_kernel), 1 = producer/consumer wavefronts with
-// 128-row tiles, 2 = 256-row tiles where the layer has them
+// 128-row tiles, 2 = 256-row tiles where the layer has them, 3 / 4 = the same with the wide (pixel-quad) form where the
+// plane allows it
 static int pc_mode() {
     static const int m = [] { const char* e = getenv("SCAT_PC"); return e ? atoi(e) : 1; }();
     return m;
 }
 
-template <int MI, bool TF, int DIAG = 0>
+template <int MI, bool TF, int DIAG = 0, bool W4 = false>
 static void launch_pw_pc(const PwDesc& d, const OutDesc& dc, hipStream_t st) {
     constexpr int BM = 128 * MI, BN = 128;
     const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, BN);
     constexpr size_t lds_bytes = (size_t)3 * 12 * BN * 16;
-    auto kern = conv1x1_pc_kernel<MI, TF, DIAG>;
+    auto kern = conv1x1_pc_kernel<MI, TF, DIAG, W4>;
     static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes) == hipSuccess);
     (void)once;
@@ -944,8 +1059,31 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
             if (cfg == 0 && tiles(128, 128) < thin) cfg = 1;          // (SCAT_PW_THIN: 64x128 below that many tiles)
         }
         const int pc = pc_mode();
+        // wide form: pointwise, whole pixel quads inside one image, 16-byte aligned planes, NCHW output
+        const bool w4ok = HW % 4 == 0 && ((uintptr_t)dst & 15) == 0 && (!bias || dc.bias_mode == 1);
+        if (cfg == 0 && pc >= 3 && w4ok) {
+            const bool big = pc == 4 && M >= 256;
+            set_kernel_label("conv1x1_split_pc4_%dx128x32%s", big ? 256 : 128, in_scale ? "_tf" : "");
+            if (!in_scale && !big && tuning() >= 100) {
+                switch (tuning() - 100) {
+                case 1: launch_pw_pc<1, false, 1, true>(d, dc, st); break;
+                case 2: launch_pw_pc<1, false, 2, true>(d, dc, st); break;
+                case 4: launch_pw_pc<1, false, 4, true>(d, dc, st); break;
+                case 8: launch_pw_pc<1, false, 8, true>(d, dc, st); break;
+                case 11: launch_pw_pc<1, false, 11, true>(d, dc, st); break;
+                case 20: launch_pw_pc<1, false, 20, true>(d, dc, st); break;
+                default: launch_pw_pc<1, false, 0, true>(d, dc, st);
+                }
+            } else if (in_scale) {
+                if (big) launch_pw_pc<2, true, 0, true>(d, dc, st); else launch_pw_pc<1, true, 0, true>(d, dc, st);
+            } else {
+                if (big) launch_pw_pc<2, false, 0, true>(d, dc, st); else launch_pw_pc<1, false, 0, true>(d, dc, st);
+            }
+            SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
+            return SCAT_OK;
+        }
         if (cfg == 0 && pc) {
-            const bool big = pc == 2 && M >= 256;
+            const bool big = (pc == 2 || pc == 4) && M >= 256;
             set_kernel_label("conv1x1_split_pc%dx128x32%s", big ? 256 : 128, in_scale ? "_tf" : "");
             if (!in_scale && !big && tuning() >= 100) {      // timing experiments (SCAT_TUNE=100+DIAG)
                 switch (tuning() - 100) {

@@ -95,6 +95,7 @@ class GradBuckets:
         self._sent = set()
         self._comm_stream = None   # the stream every collective is ordered after (device runs only)
         self._checks = []
+        self._pad_idx = None
         self._host_stage = {}
         self.check = _dp_check()
         self._avg_ok = False
@@ -220,7 +221,7 @@ class GradBuckets:
     # ---- collectives
     def _allreduce(self, t, name="?"):
         if self.world <= 1:
-            if self.check and t.is_cuda:
+            if self.check:
                 self._checks.append((name, torch.isnan(t).any()))
             return
         backend = dist.get_backend(self.pg)
@@ -246,6 +247,8 @@ class GradBuckets:
                     self._pending.append(("staged", (ev, host), t))
             return
         # gloo on host tensors (CPU tests): SUM, scaled by 1/N in wait_pending()
+        if self.check:
+            self._checks.append((name, torch.isnan(t).any()))
         self._pending.append(("work", dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), t))
 
     def _gather(self, params):
@@ -338,6 +341,12 @@ class GradBuckets:
             p.grad = None
         if self.check:
             self.flat_grad.fill_(float("nan"))
+            if self._pad_idx is None:      # the alignment padding between parameters is nobody's to write: keep it 0
+                keep = torch.ones(self.flat_grad.numel(), dtype=torch.bool)
+                for off, k in self.slot.values():
+                    keep[off:off + k] = False
+                self._pad_idx = keep.nonzero().flatten().to(self.flat_grad.device)
+            self.flat_grad.index_fill_(0, self._pad_idx, 0.0)
 
 
 def init_distributed():

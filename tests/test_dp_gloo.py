@@ -218,6 +218,41 @@ def test_two_rank_buckets():
     assert [r for r, _ in got] == [0, 1]
 
 
+def test_stream_order_self_check(monkeypatch):
+    """SCAT_DP_CHECK=1: the flat gradient buffer is poisoned with NaN before every backward and every bucket is tested
+    in front of its collective — a bucket declared ready before all of its slices were written is reported (this is
+    how a gradient kernel on a stream nobody joined shows up); the alignment padding is nobody's to write."""
+    from scat_amd.dp import BACKBONE_BUCKETS, GradBuckets
+
+    monkeypatch.setenv("SCAT_DP_CHECK", "1")
+    net = _Tiny()
+    b = GradBuckets(net)
+    assert b.check
+    for trial in range(2):
+        b.zero_grad()
+        assert torch.isnan(b.view_for(net.regressor.weight)).all()
+        (net(torch.randn(4, 6)).sum()).backward()
+        bb = {n: p for n, p in net.named_parameters() if n.startswith("main_encoder.")}
+        saved = {n: p.grad.clone() for n, p in bb.items()}
+        for p in bb.values():
+            p.grad = None
+        b.begin_backbone()
+        for bucket in BACKBONE_BUCKETS:
+            for n, p in bb.items():
+                key = n.split(".")[1]
+                if (key == bucket) or (bucket == "stem" and key == "conv1"):
+                    if trial == 1 and n == "main_encoder.layer3.bias":
+                        continue                  # "its kernel has not run yet"
+                    b.view_for(p).copy_(saved[n])
+            b.ready((bucket,))
+        b.adopt(list(bb.values()))
+        if trial == 0:
+            b.finish()
+        else:
+            with pytest.raises(RuntimeError, match="layer3"):
+                b.finish()
+
+
 def test_single_process_buckets_are_storage_only():
     from scat_amd.dp import GradBuckets
 
