@@ -71,6 +71,12 @@ int64_t scat_conv2d_fwd_split_ws(int Cout, int Cin, int KH, int KW);
 int scat_conv2d_fwd_split(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
                           int Cout, int KH, int KW, int stride, int pad, const float* in_scale, const float* in_shift,
                           int in_relu, void* ws, int64_t ws_bytes, int w_ready, void* stream);
+/* The ResNet stem, Conv2d(3, Cout, 7, stride 2, padding 3, bias=False) (models/resnet.py:105), on split-operand
+ * products: contraction over (kh, c, kw) with kw padded to 8, so a k-octet is 8 consecutive input pixels.
+ * y[B,Cout,OH,OW]; ws: scat_conv7x7_s2_fwd_split_ws(Cout) bytes.  Needs scat_get_math_mode() == 1. */
+int64_t scat_conv7x7_s2_fwd_split_ws(int Cout);
+int scat_conv7x7_s2_fwd_split(const float* x, const float* w, float* y, int B, int H, int W, int Cout, void* ws,
+                              int64_t ws_bytes, void* stream);
 /* Pointwise (1x1, stride 1, pad 0) conv: dst[B,M,HW] (+)= A[M,C] . relu(src[B,C,HW]*scale+shift) (+ bias[M]).
  * Weights go straight from L2 to the MFMA operand registers, activations through LDS 32 channels per barrier.
  * transposed = 0 (forward): w = [M,C] = the conv weight [Cout,Cin];  transposed = 1 (data gradient): w = [C,M] is

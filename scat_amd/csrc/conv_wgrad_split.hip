@@ -245,6 +245,222 @@ __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc
     store_tile<MI, NI, BM, BN, 2, 2>(acc, dc, d.Cout, d.N, i0, j0, z);
 }
 
+// ---------------------------------------------------------------- producer / consumer wave specialisation
+//
+// The weight gradient splits BOTH operands on their way into LDS: 16 elements of staging (load, mask, fused transform,
+// three-way split, three 16-byte LDS writes: ~130 VALU) per thread for every 24 MFMAs, and its split-K grids are sized
+// for ~1.5 workgroups per CU (wgrad_split_plan) — with one or two in-order wavefronts per SIMD the matrix pipe idles
+// while its wavefront splits (measured: half of what the same MFMA stream reaches alone, tools/mfma_probe.hip).  Here
+// a 512-thread workgroup has four consumer wavefronts (fragments from LDS, MFMAs: nothing else) and four producer
+// wavefronts (everything else, two register sets, LDS three stages deep); one barrier per 16-pixel stage.
+template <int KK, bool TF, bool S2, bool DSA>
+__global__ __launch_bounds__(512, 4) void wgrad_pc_kernel(WgDesc d, OutDesc dc) {
+    constexpr int MI = 2, NI = 2, BM = 128, BN = 128;
+    constexpr int OSA = BM + 8, OSB = BN + 8;
+    constexpr int BUF = 6 * (OSA + OSB);               // u32x4 per stage buffer
+    extern __shared__ __align__(16) float lds[];       // [3 buffers][A: 6 slabs of OSA | B: 6 slabs of OSB] x 16 B
+    u32x4* const L0 = (u32x4*)lds;
+
+    const int mt = (d.Cout + BM - 1) / BM, nt = (d.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int i0 = (tile % mt) * BM, j0 = (tile / mt) * BN;
+    const int z = blockIdx.z;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int sbeg = z * d.spz, send = min(sbeg + d.spz, (d.U + 1) >> 1);
+    const int nst = send > sbeg ? send - sbeg : 0;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------ producer: (row, octet) = (ptid >> 1, ptid & 1)
+        const int tid = threadIdx.x - 256;
+        const __amdgpu_buffer_rsrc_t rsa = make_rsrc(d.dy, d.ndy), rsb = make_rsrc(d.x, d.nx);
+        const int srow = tid >> 1, so = tid & 1;
+        const int arow = i0 + srow;
+        const bool a_ok = arow < d.Cout;
+        const int col = j0 + srow;
+        const bool b_ok = col < d.N;
+        int ci = 0, kh = 1, kw = 1;
+        if (KK == 9) {
+            const uint32_t c = d.dKK.div((uint32_t)(b_ok ? col : 0));
+            const int tap = (b_ok ? col : 0) - (int)c * 9;
+            ci = (int)c; kh = tap / 3; kw = tap - 3 * kh;
+        } else {
+            ci = b_ok ? col : 0;
+        }
+        if (S2 && KK == 1) { kh = 0; kw = 0; }
+        const int bshift = (kh - 1) * d.W + (kw - 1);
+        float bsc = 1.f, bsh = 0.f;
+        if (TF && b_ok) { bsc = d.scale[ci]; bsh = d.shift[ci]; }
+        const __amdgpu_buffer_rsrc_t rsa2 = make_rsrc(DSA ? d.dy2 : d.dy, DSA ? d.ndy : 0);
+        float aca = 1.f, acb = 0.f, acc_ = 0.f;
+        if (DSA && a_ok) { aca = d.coef[arow]; acb = d.coef[d.Cout + arow]; acc_ = d.coef[2 * d.Cout + arow]; }
+        float araw[2][8], braw[2][8];
+        float araw2[DSA ? 2 : 1][8];
+        uint32_t amask[2] = {0, 0}, bmask[2] = {0, 0};
+        auto load_stage = [&](int s, auto set_tag) {
+            constexpr int Q = decltype(set_tag)::value;
+            const int u = 2 * s + so;
+            const bool in = s < send && u < d.U;
+            const uint32_t uu = in ? (uint32_t)u : 0u;
+            const uint32_t n = d.dNO.div(uu);
+            const int r0 = 8 * (int)(uu - n * (uint32_t)d.NO);
+            const int cnt = in ? min(8, d.OHW - r0) : 0;
+            const uint32_t live = (1u << cnt) - 1u;
+            {
+                const int off = (a_ok && cnt > 0) ? (((int)n * d.Cout + arow) * d.OHW + r0) * 4 : OOB;
+                load8(rsa, off, a_ok ? live : 0u, d.ndy, araw[Q]);
+                if constexpr (DSA) load8(rsa2, off, a_ok ? live : 0u, d.ndy, araw2[Q]);
+                amask[Q] = a_ok ? live : 0u;
+            }
+            if constexpr (!S2) {
+                uint32_t m = live;
+                if (KK == 9) {
+                    const int y0 = (int)d.dW.div((uint32_t)r0), x0 = r0 - y0 * d.W;
+                    uint32_t v = 0;
+                    int y = y0 + kh - 1, x = x0 + kw - 1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
+                        v |= (ok ? 1u : 0u) << e;
+                        ++x;
+                        if (x == d.W + kw - 1) { x = kw - 1; ++y; }
+                    }
+                    m &= v;
+                }
+                m = b_ok ? m : 0u;
+                const int off = m ? (((int)n * d.Cin + ci) * d.HW + r0 + bshift) * 4 : OOB;
+                load8(rsb, off, m, d.nx, braw[Q]);
+                bmask[Q] = m;
+            } else {
+                int oy = (int)d.dW.div((uint32_t)r0), ox = r0 - oy * d.OW;
+                const int base = ((int)n * d.Cin + ci) * d.HW;
+                uint32_t m = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int sy = d.stride * oy + kh - d.pad, sx = d.stride * ox + kw - d.pad;
+                    const bool ok = b_ok && ((live >> e) & 1u) && (unsigned)sy < (unsigned)d.H && (unsigned)sx < (unsigned)d.W;
+                    braw[Q][e] = __uint_as_float(
+                        __builtin_amdgcn_raw_buffer_load_b32(rsb, ok ? (base + sy * d.W + sx) * 4 : OOB, 0, 0));
+                    m |= (ok ? 1u : 0u) << e;
+                    if (++ox == d.OW) { ox = 0; ++oy; }
+                }
+                bmask[Q] = m;
+            }
+        };
+        auto store_stage = [&](u32x4* buf, auto set_tag) {
+            constexpr int Q = decltype(set_tag)::value;
+            {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = araw[Q][e];
+                    if constexpr (DSA) t = fmaf(aca, t, fmaf(acb, araw2[Q][e], acc_));
+                    v[e] = ((amask[Q] >> e) & 1u) ? t : 0.f;
+                }
+                u32x4 hi, mid, lo;
+                split3x8(v, hi, mid, lo);
+                u32x4* p = buf + so * OSA + srow;
+                p[0] = hi; p[2 * OSA] = mid; p[4 * OSA] = lo;
+            }
+            {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = braw[Q][e];
+                    if constexpr (TF) {
+                        t = fmaf(t, bsc, bsh);
+                        t = d.relu ? fmaxf(t, 0.f) : t;
+                    }
+                    v[e] = ((bmask[Q] >> e) & 1u) ? t : 0.f;
+                }
+                u32x4 hi, mid, lo;
+                split3x8(v, hi, mid, lo);
+                u32x4* p = buf + 6 * OSA + so * OSB + srow;
+                p[0] = hi; p[2 * OSB] = mid; p[4 * OSB] = lo;
+            }
+        };
+        // stage sbeg + k: register set k & 1, LDS buffer k % 3
+        load_stage(sbeg, S0{});
+        load_stage(sbeg + 1, S1{});
+        store_stage(L0, S0{});
+        load_stage(sbeg + 2, S0{});
+        store_stage(L0 + BUF, S1{});
+        __syncthreads();
+        int wb = 2;
+        auto iter = [&](int k, auto par_tag) {
+            constexpr int P = decltype(par_tag)::value;
+            load_stage(sbeg + k + 3, std::integral_constant<int, P ^ 1>{});
+            store_stage(L0 + wb * BUF, par_tag);
+            wb = wb == 2 ? 0 : wb + 1;
+            __syncthreads();
+        };
+        for (int k = 0; k < nst; k += 2) {
+            iter(k, S0{});
+            if (k + 1 < nst) iter(k + 1, S1{});
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- consumer (2 x 2 wavefronts, 64 x 64 each)
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int afrag = lh * OSA + wm * (BM / 2) + l31, bfrag = 6 * OSA + lh * OSB + wn * (BN / 2) + l31;
+    __syncthreads();
+    // fragments (a = 0) and (b = 0) of a stage are read during the previous stage's last MFMA group: the stage was
+    // published a barrier earlier (three buffers), so the first group of every stage starts right after the barrier
+    u32x4 a0[3], b0[3], a1[3], b1[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { a0[p] = L0[afrag + p * 2 * OSA]; b0[p] = L0[bfrag + p * 2 * OSB]; }
+    int rb = 0;
+    for (int k = 0; k < nst; ++k) {
+        const u32x4* cur = L0 + rb * BUF;
+        rb = rb == 2 ? 0 : rb + 1;
+        const u32x4* nxt = L0 + rb * BUF;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b1[p] = cur[bfrag + p * 2 * OSB + 32];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a1[p] = cur[afrag + p * 2 * OSA + 32];
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = mfma_split(a0, b0, acc[0][0]);
+        acc[0][1] = mfma_split(a0, b1, acc[0][1]);
+        acc[1][0] = mfma_split(a1, b0, acc[1][0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { a0[p] = nxt[afrag + p * 2 * OSA]; b0[p] = nxt[bfrag + p * 2 * OSB]; }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[1][1] = mfma_split(a1, b1, acc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    store_tile<MI, NI, BM, BN, 2, 2>(acc, dc, d.Cout, d.N, i0, j0, z);
+}
+
+template <int KK, bool TF, bool S2, bool DSA>
+static void launch_wg_pc(const WgDesc& d, const OutDesc& dc, int splits, hipStream_t st) {
+    const int mt = cdiv(d.Cout, 128), nt = cdiv(d.N, 128);
+    constexpr size_t lds_bytes = (size_t)3 * 6 * (128 + 8 + 128 + 8) * 16;
+    auto kern = wgrad_pc_kernel<KK, TF, S2, DSA>;
+    static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds_bytes) == hipSuccess);
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3(mt * nt, 1, splits), dim3(512), lds_bytes, st, d, dc);
+}
+
+// SCAT_WG_PC=0: every wavefront stages and multiplies; 1: producer / consumer wavefronts for the 128 x 128 tiles
+static int wg_pc_mode() {
+    static const int m = [] { const char* e = getenv("SCAT_WG_PC"); return e ? atoi(e) : 1; }();
+    return m;
+}
+
 template <int KK, int MI, int NI, bool TF, bool S2, bool DSA = false>
 static void launch_wg(const WgDesc& d, const OutDesc& dc, int splits, hipStream_t st) {
     constexpr int BM = 64 * MI, BN = 64 * NI;
@@ -316,6 +532,23 @@ void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, f
     dc.n = (int64_t)p.M * p.N;
     set_kernel_label("wgrad%s%s_split_%dx%dx16%s%s_split%d", KK == 9 ? "3x3" : "1x1", stride == 2 ? "_s2" : "", 64 * p.mi,
                      64 * p.ni, in_scale ? "_tf" : "", dy2 ? "_bnb" : "", p.splits);
+    if (wg_pc_mode() && p.mi == 2 && p.ni == 2) {
+        const bool tf = in_scale != nullptr;
+        set_kernel_label("wgrad%s%s_split_pc128x128x16%s%s_split%d", KK == 9 ? "3x3" : "1x1", stride == 2 ? "_s2" : "",
+                         in_scale ? "_tf" : "", dy2 ? "_bnb" : "", p.splits);
+        if (dy2) {
+            if (tf) launch_wg_pc<1, true, false, true>(d, dc, p.splits, st);
+            else launch_wg_pc<1, false, false, true>(d, dc, p.splits, st);
+        } else if (stride == 2) {
+            if (KK == 9) { if (tf) launch_wg_pc<9, true, true, false>(d, dc, p.splits, st); else launch_wg_pc<9, false, true, false>(d, dc, p.splits, st); }
+            else { if (tf) launch_wg_pc<1, true, true, false>(d, dc, p.splits, st); else launch_wg_pc<1, false, true, false>(d, dc, p.splits, st); }
+        } else if (KK == 9) {
+            if (tf) launch_wg_pc<9, true, false, false>(d, dc, p.splits, st); else launch_wg_pc<9, false, false, false>(d, dc, p.splits, st);
+        } else {
+            if (tf) launch_wg_pc<1, true, false, false>(d, dc, p.splits, st); else launch_wg_pc<1, false, false, false>(d, dc, p.splits, st);
+        }
+        return;
+    }
     if (dy2) {      // 1x1 / stride 1 only (checked by the caller)
         if (in_scale) launch_wg_dsa<true>(p.mi, p.ni, d, dc, p.splits, st);
         else launch_wg_dsa<false>(p.mi, p.ni, d, dc, p.splits, st);

@@ -200,6 +200,7 @@ def conv_out_hw(H, W, k, stride, pad):
     return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
 
 
+STEM_SPLIT = os.environ.get("SCAT_STEM_SPLIT", "1") != "0"   # the 7x7/s2 stem on split-operand products (0: fp32 engine)
 HALO = os.environ.get("SCAT_HALO", "1") != "0"   # 3x3/s1/p1 through the LDS-halo kernel (0: generic gather, for A/B runs)
 
 
@@ -239,6 +240,12 @@ def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, b
         _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_fwd_split, _p(x), _p(w), _p(bias), _p(y), B,
               Cin, H, W, Cout, KH, KW, stride, pad, _p(in_scale), _p(in_shift), int(in_relu), _p(ws), ws.numel(),
               rdy, _stream())
+        return y
+    if (KH == 7 and KW == 7 and stride == 2 and pad == 3 and Cin == 3 and bias is None and in_scale is None
+            and lib().scat_get_math_mode() == 1 and STEM_SPLIT):
+        ws = workspace(lib().scat_conv7x7_s2_fwd_split_ws(Cout), x.device, "stem")
+        _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv7x7_s2_fwd_split, _p(x), _p(w), _p(y), B, H, W,
+              Cout, _p(ws), ws.numel(), _stream())
         return y
     if _halo_ok(KH, KW, stride, pad, Cin, W) and bias is None:
         ws, rdy = _wp_ws(wp, w, WPREP_CONV3X3_FWD, Cout, Cin, 3, 3, 1, lib().scat_conv3x3_s1_ws(Cout, Cin), x.device)

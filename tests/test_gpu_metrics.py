@@ -56,8 +56,8 @@ def test_reference_checkpoint_round_trip(golden, tmp_path):
         assert np.allclose(digest(own[k].float(), 4)[:4], dg, rtol=1e-6, atol=1e-9), k
     f2 = tmp_path / "mirror.pth"
     torch.save(own, f2)
-    net2 = make_encoder(77)
-    net2.load_state_dict(torch.load(f2, map_location="cuda"), strict=True)
+    net2 = EncoderTransformer(opt_ns(), T(synth.mean_params(51))).cuda()   # (mean_params is a plain attribute, not in
+    net2.load_state_dict(torch.load(f2, map_location="cuda"), strict=True)  # the checkpoint: hand_net.py:321)
     net2.eval()
     random.seed(3)
     with torch.no_grad():

@@ -191,7 +191,9 @@ def test_trainstep_golden(golden):
         assert rel_err(pred, g[f"s{step}:pred"]) < (1e-4 if step == 1 else 2e-2)
         assert rel_err(net.regressor.bias, g[f"s{step}:regressor.bias"]) < 1e-3
         assert rel_err(net.main_encoder.bn1.running_mean, g[f"s{step}:bn1.running_mean"]) < 1e-4
-        assert digest_err(digest(net.regressor.weight, 32), g[f"s{step}:regressor.weight"]) < 2e-3
+        # (Adam moves every weight by +-lr = 5e-4 whatever |g| is: a near-zero gradient whose sign differs between two
+        # fp32 evaluations moves a sampled weight by 1e-3 -- measured 1.1e-3 .. 2.5e-3 across math modes / stem kernels)
+        assert digest_err(digest(net.regressor.weight, 32), g[f"s{step}:regressor.weight"]) < (2e-3 if step == 1 else 5e-3)
         assert digest_err(digest(net.main_encoder.layer3[0].conv2.weight, 32),
                           g[f"s{step}:layer3.0.conv2.weight"]) < (1e-4 if step == 1 else 5e-2)
     assert int(net.main_encoder.bn1.num_batches_tracked) == int(g["nbt"]) == 2

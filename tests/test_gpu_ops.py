@@ -149,6 +149,27 @@ def test_conv3x3_halo(ops, math_mode, math, B, cin, cout, H, W):
         ops.HALO = True
 
 
+@pytest.mark.parametrize("B,cout,H,W", [(2, 64, 224, 224), (3, 64, 38, 54), (1, 96, 32, 18), (2, 160, 16, 16)])
+def test_stem_conv7x7_split(ops, math_mode, B, cout, H, W):
+    """models/resnet.py:105: Conv2d(3, 64, 7, stride 2, padding 3) on the split-operand kernel (k-octet = 8 consecutive
+    input pixels of one (kh, c)): left / right / top / bottom padding, ragged pixel tiles, more than one row tile,
+    against fp64 torch and against the fp32 engine."""
+    math_mode(1)
+    x = t(90, "x", (B, 3, H, W))
+    w = t(91, "w", (cout, 3, 7, 7), std=(2.0 / 147) ** 0.5)
+    y = F.conv2d(x.double(), w.double(), stride=2, padding=3)
+    yg = ops.conv2d_fwd(g(x), g(w), 2, 3)
+    assert ops.lib().scat_last_kernel().decode().startswith("conv7x7_s2_split")
+    assert rel_err(yg, y) < 2e-5
+    try:
+        ops.STEM_SPLIT = False
+        y0 = ops.conv2d_fwd(g(x), g(w), 2, 3)
+        assert not ops.lib().scat_last_kernel().decode().startswith("conv7x7_s2_split")
+    finally:
+        ops.STEM_SPLIT = True
+    assert rel_err(yg, y0.cpu()) < 2e-5
+
+
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 48, 80, 9, 13), (1, 16, 208, 5, 64), (3, 32, 64, 7, 7),
                                              (2, 64, 144, 30, 4), (5, 256, 128, 14, 14)])
 @pytest.mark.parametrize("math", [0, 1])

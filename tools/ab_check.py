@@ -14,9 +14,11 @@ import bench
 from scat_amd.trainer import TrainStep
 B = int(sys.argv[1])
 dev = torch.device("cuda", 0)
-net = bench.make_net(1, dev)
+net = bench.make_net("resnet50", 1, dev)
 ts = TrainStep(net, lr=1e-4)
-x, lab = bench.build_inputs(B, 100, dev)
+u8, lab = bench.build_inputs(B, 100, dev)
+from scat_amd import ops as _ops
+x = _ops.preprocess_u8(u8, (224, 224))
 random.seed(3)
 out = []
 for i in range(4):

@@ -22,9 +22,11 @@ def main():
     from scat_amd.trainer import TrainStep
 
     dev = torch.device("cuda", 0)
-    net = bench.make_net(1, dev)
+    net = bench.make_net("resnet50", 1, dev)
     ts = TrainStep(net, lr=5e-4)
-    x, lab = bench.build_inputs(a.batch, 100, dev)
+    u8, lab = bench.build_inputs(a.batch, 100, dev)
+    from scat_amd import ops as _ops
+    x = _ops.preprocess_u8(u8, (224, 224))
     if a.hi:
         torch.cuda.synchronize()
         torch.cuda.set_stream(torch.cuda.Stream(priority=-1))

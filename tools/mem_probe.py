@@ -10,9 +10,11 @@ import bench  # noqa: E402
 from scat_amd.trainer import TrainStep  # noqa: E402
 
 dev = torch.device("cuda", 0)
-net = bench.make_net(1, dev)
+net = bench.make_net("resnet50", 1, dev)
 ts = TrainStep(net, lr=5e-4)
-x, lab = bench.build_inputs(96, 100, dev)
+u8, lab = bench.build_inputs(96, 100, dev)
+from scat_amd import ops as _ops
+x = _ops.preprocess_u8(u8, (224, 224))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 900
 t0 = time.perf_counter()
 for i in range(n + 1):

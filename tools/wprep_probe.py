@@ -11,9 +11,11 @@ from scat_amd import ops  # noqa: E402
 from scat_amd.trainer import TrainStep  # noqa: E402
 
 dev = torch.device("cuda", 0)
-net = bench.make_net(1, dev)
+net = bench.make_net("resnet50", 1, dev)
 ts = TrainStep(net, lr=5e-4)
-x, lab = bench.build_inputs(8, 100, dev)
+u8, lab = bench.build_inputs(8, 100, dev)
+from scat_amd import ops as _ops
+x = _ops.preprocess_u8(u8, (224, 224))
 for _ in range(3):
     ts(x, lab)
 torch.cuda.synchronize()
