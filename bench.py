@@ -111,6 +111,44 @@ def build_inputs(batch, seed, device, src=256):
     return u8, lab
 
 
+def h2d_pipeline_rate(step, u8, lab, steps):
+    """PCIe-inclusive rate (never ``value``): the uint8 source batch starts in PINNED HOST memory every step and is
+    copied by a side stream into one of two device buffers while the previous step computes (what
+    train.py:152-153 does synchronously with a 57.8 MB fp32 batch is an 18.9 MB uint8 copy here, because the
+    normalise + resize runs on the device)."""
+    dev = u8.device
+    host = [u8.cpu().pin_memory(), u8.cpu().pin_memory()]
+    devb = [torch.empty_like(u8), torch.empty_like(u8)]
+    copy = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream()
+    ready = [None, None]
+    freed = [None, None]
+
+    def issue(i):
+        b = i & 1
+        with torch.cuda.stream(copy):
+            if freed[b] is not None:
+                copy.wait_event(freed[b])          # the step that read this buffer two steps ago has finished
+            devb[b].copy_(host[b], non_blocking=True)
+            ready[b] = copy.record_event()
+
+    issue(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i + 1 < steps:
+            issue(i + 1)
+        b = i & 1
+        main.wait_event(ready[b])
+        step(devb[b], lab)
+        freed[b] = main.record_event()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"images_per_s": round(u8.shape[0] * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "h2d_mb_per_step": round(u8.numel() / 1e6, 1),
+            "note": "uint8 source batch from pinned host memory, double-buffered on a copy stream under the previous step"}
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -262,6 +300,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--h2d", action="store_true", help="also time the steps with the source batch coming from pinned "
+                    "host memory (double-buffered H2D; reported as config.pcie_inclusive, never as value)")
     a = ap.parse_args()
 
     # distributed first: RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run, the device is chosen and the
@@ -314,6 +354,7 @@ def main():
     note(f"{a.steps} steps in {dt:.3f} s = {a.batch * world * a.steps / dt:.1f} img/s (median step {med:.3f} ms); "
          "roofline + CPU baseline legs")
 
+    pcie = h2d_pipeline_rate(step, u8, lab, a.steps) if a.h2d else None
     roof, roof_hbm, table = None, None, {}
     if not a.no_roofline:
         # every rank runs the instrumented step (it contains the gradient all-reduces); rank 0 reports
@@ -347,7 +388,7 @@ def main():
                        "products": ("fp32 operands as 3 bf16 terms, 6 bf16 MFMA terms per product, fp32 accumulate "
                                     "(error <= 2^-25 per product; DESIGN.md 3.0)" if lib().scat_get_math_mode() == 1
                                     else "fp32 MFMA"),
-                       "whole_step_tflops_per_gpu": round(step_tf, 2)},
+                       "whole_step_tflops_per_gpu": round(step_tf, 2), "pcie_inclusive": pcie},
             "roofline": roof, "roofline_hbm": roof_hbm, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -71,6 +71,13 @@ int64_t scat_conv2d_fwd_split_ws(int Cout, int Cin, int KH, int KW);
 int scat_conv2d_fwd_split(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
                           int Cout, int KH, int KW, int stride, int pad, const float* in_scale, const float* in_shift,
                           int in_relu, void* ws, int64_t ws_bytes, int w_ready, void* stream);
+/* One transformer layer's qkv projection + softmax attention in one launch (models/vision_transformer.py:61-76):
+ * qkv[B*n,3*heads*64] = h[B*n,dim] . wqkv^T; attn[B,heads,n,n] = softmax(scale q k^T); ao[B*n,heads*64] = attn . v
+ * ('b n (h d)').  One workgroup per (block of 128/n images, head): the block's projection stays in LDS for its
+ * attention.  n <= 32, dim % 4 == 0, head dim 64, scat_get_math_mode() == 1.  ws: scat_vit_qkv_attn_fwd_ws bytes. */
+int64_t scat_vit_qkv_attn_fwd_ws(int dim, int heads);
+int scat_vit_qkv_attn_fwd(const float* h, const float* wqkv, float* qkv, float* attn, float* ao, int B, int n, int dim,
+                          int heads, float scale, void* ws, int64_t ws_bytes, void* stream);
 /* The ResNet stem, Conv2d(3, Cout, 7, stride 2, padding 3, bias=False) (models/resnet.py:105), on split-operand
  * products: contraction over (kh, c, kw) with kw padded to 8, so a k-octet is 8 consecutive input pixels.
  * y[B,Cout,OH,OW]; ws: scat_conv7x7_s2_fwd_split_ws(Cout) bytes.  Needs scat_get_math_mode() == 1. */

@@ -60,8 +60,12 @@ def mixer_forward(x: torch.Tensor, cfgs: List[LayerCfg], params: List[torch.Tens
         wqkv, wout, bout = p[k], p[k + 1], p[k + 2]
         k += 3
         inner = cfg.heads * cfg.dim_head
-        qkv = ops.linear_fwd(h, wqkv)
-        ao, attn = ops.attention_fwd(qkv.view(B, n, 3 * inner), cfg.heads, cfg.dim_head, cfg.scale)
+        if h.is_cuda and ops.vit_fused_ok(n, h.shape[1], cfg.dim_head):
+            # projection + attention in one launch (csrc/vit_fused.hip): the block's q, k, v stay in LDS
+            qkv, ao, attn = ops.qkv_attention_fwd(h, wqkv, B, n, cfg.heads, cfg.scale)
+        else:
+            qkv = ops.linear_fwd(h, wqkv)
+            ao, attn = ops.attention_fwd(qkv.view(B, n, 3 * inner), cfg.heads, cfg.dim_head, cfg.scale)
         if cfg.post_ln:
             gp, bp = p[k], p[k + 1]
             k += 2

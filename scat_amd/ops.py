@@ -579,6 +579,32 @@ def attention_fwd(qkv, heads, dim_head, scale):
     return out, attn
 
 
+# qkv projection + attention of a layer in one launch (csrc/vit_fused.hip).  Off by default: measured at batch 96
+# (tools/vit_fused_bench.py) the fused launch takes 87-97 / 59-63 / 42-46 us for dim 784 / 392 / 196 against 73 / 51 / 36 us
+# for the two launches it replaces — 128 workgroups of 21-row images cannot feed the matrix pipe better than the
+# engine's 64x64 tiles do, and the step time does not move (the token path hides under layer3/layer4).
+VIT_FUSED = os.environ.get("SCAT_VIT_FUSED", "0") != "0"
+
+
+def vit_fused_ok(n, dim, dim_head):
+    return VIT_FUSED and n <= 32 and dim % 4 == 0 and dim_head == 64 and lib().scat_get_math_mode() == 1
+
+
+def qkv_attention_fwd(h2d, wqkv, B, n, heads, scale):
+    """h2d[B*n,dim], wqkv[3*heads*64,dim] -> (qkv[B*n,3*heads*64], out[B,n,heads*64], attn[B,heads,n,n]) — one launch
+    per layer: each workgroup projects one head of a block of 128/n images and runs their attention from LDS"""
+    _chk(h2d, wqkv)
+    dim = h2d.shape[1]
+    inner = heads * 64
+    qkv = torch.empty((B * n, 3 * inner), dtype=torch.float32, device=h2d.device)
+    out = torch.empty((B, n, inner), dtype=torch.float32, device=h2d.device)
+    attn = torch.empty((B, heads, n, n), dtype=torch.float32, device=h2d.device)
+    ws = workspace(lib().scat_vit_qkv_attn_fwd_ws(dim, heads), h2d.device, "vit")
+    _prof(2.0 * B * n * 3 * inner * dim, lib().scat_vit_qkv_attn_fwd, _p(h2d), _p(wqkv), _p(qkv), _p(attn), _p(out), B, n,
+          dim, heads, scale, _p(ws), ws.numel(), _stream())
+    return qkv, out, attn
+
+
 def attention_bwd(dout, qkv, attn, heads, dim_head, scale):
     _chk(dout, qkv, attn)
     B, n, _ = qkv.shape

@@ -575,6 +575,31 @@ def test_attention_core(ops, B, n, heads):
     assert rel_err(ops.attention_bwd(g(do), g(qkv.detach()), ag, heads, d, scale), dqkv) < 2e-5
 
 
+@pytest.mark.parametrize("B,n,dim,heads", [(2, 21, 784, 8), (7, 21, 392, 8), (13, 21, 196, 8), (96, 21, 784, 8),
+                                            (5, 16, 200, 2), (3, 32, 72, 16)])
+def test_vit_qkv_attention_fused(ops, math_mode, B, n, dim, heads):
+    """One launch per transformer layer for the qkv projection + softmax attention (models/vision_transformer.py:
+    61-76): a workgroup = one head of a block of 128/n images, q/k/v stay in LDS.  Full blocks, a ragged last block,
+    feature counts that are not multiples of 16 or 32, against fp64 torch and the unfused kernels."""
+    math_mode(1)
+    d = 64
+    inner = heads * d
+    h = t(110, "h", (B * n, dim))
+    w = t(111, "w", (3 * inner, dim), std=dim ** -0.5)
+    scale = d ** -0.5
+    qkv_ref = h.double() @ w.double().t()
+    q, k, v = (z.reshape(B, n, heads, d).permute(0, 2, 1, 3) for z in qkv_ref.split(inner, dim=-1))
+    attn = (q @ k.transpose(-1, -2) * scale).softmax(-1)
+    out = (attn @ v).permute(0, 2, 1, 3).reshape(B, n, inner)
+    qg, og, ag = ops.qkv_attention_fwd(g(h), g(w), B, n, heads, scale)
+    assert ops.lib().scat_last_kernel().decode().startswith("vit_qkv_attn_fused")
+    assert rel_err(qg, qkv_ref) < 2e-5
+    assert rel_err(ag, attn) < 2e-5 and rel_err(og, out) < 2e-5
+    q0 = ops.linear_fwd(g(h), g(w))
+    o0, a0 = ops.attention_fwd(q0.view(B, n, 3 * inner), heads, d, scale)
+    assert rel_err(qg, q0.cpu()) < 2e-5 and rel_err(og, o0.cpu()) < 2e-5 and rel_err(ag, a0.cpu()) < 2e-5
+
+
 def test_elementwise_tokens(ops):
     x = t(37, "x", (4, 21, 784)).requires_grad_(True)
     y = F.gelu(x)
