@@ -161,14 +161,14 @@ def cpu_model():
 
 def cpu_baseline():
     """The CPU oracle (a torch-CPU restatement of the reference path, pinned to the reference's outputs by
-    tests/golden) on a bounded sample of the same workload: batch 96 and batch 8, every core the
-    box gives this process."""
+    tests/golden) on a bounded sample of the same workload: batch 96 and batch 8, on the cores the
+    box gives this process (16 per GPU; SCAT_CPU_THREADS overrides)."""
     from oracle import scat_oracle as O
     from scat_amd import synth
 
-    cores = len(os.sched_getaffinity(0))
-    if os.environ.get("SCAT_CPU_THREADS"):
-        cores = min(cores, int(os.environ["SCAT_CPU_THREADS"]))
+    # the box's CPU SHARE, not the host's core count: a 1-GPU box gives this process 16 cores of a much larger host
+    # (sched_getaffinity lists them all), and OpenMP threads beyond the share spin against each other for minutes
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("SCAT_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     sd = synth.to_torch(synth.encoder_transformer_state(1, 8))
     mp = torch.from_numpy(synth.mean_params(1))
@@ -202,11 +202,15 @@ def instantiation_of(label):
     if m:
         return f"conv1x1_pc_kernel<{int(m.group(1)) // 128},{tf},0>"
     m = re.search(r"_split_(\d+)x(\d+)x32", label)
-    if m:       # pointwise / taps kernel: WM = rows / 32
-        return f"conv1x1_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf},{ds}>"
+    if m:       # pointwise / taps kernel: WM = rows / 32; the stem is the same kernel with the STEM staging
+        stem = "t" if label.startswith("conv7x7_s2_split") else "f"
+        return f"conv1x1_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf},{ds},{stem}>"
     m = re.match(r"conv3x3_split_(\d+)x(\d+)x16", label)
     if m:
         return f"conv3x3_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf}>"
+    m = re.match(r"wgrad(1x1|3x3)(_s2)?_split_pc128x128x16", label)
+    if m:
+        return f"wgrad_pc_kernel<{9 if m.group(1) == '3x3' else 1},{tf},{'t' if m.group(2) else 'f'},{ds}>"
     m = re.match(r"wgrad(1x1|3x3)(_s2)?_split_(\d+)x(\d+)x16", label)
     if m:
         return (f"wgrad_split_kernel<{9 if m.group(1) == '3x3' else 1},{int(m.group(3)) // 64},{int(m.group(4)) // 64},"

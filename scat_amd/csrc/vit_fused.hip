@@ -39,7 +39,7 @@ constexpr int VF_TS = VF_COLS + 1;           // padded row of the parked project
 constexpr int VF_NT = 512, VF_NI = 9 * 256 / VF_NT + 1;      // staging items per thread (2304 per stage)
 __global__ __launch_bounds__(VF_NT) void vit_qkv_attn_kernel(VitDesc d) {
     extern __shared__ __align__(16) float lds[];
-    // during the projection: two weight stage buffers [2 chunks][3 planes][2 k-octets][192 cols] x 16 B = 36,864 B each;
+    // during the projection: three weight stage buffers [2 chunks][3 planes][2 k-octets][192 cols] x 16 B = 36,864 B each;
     // afterwards the same memory holds the projection tile [128][193] floats and the scores [IB][n][n + 1]
     u32x4* const W0 = (u32x4*)lds;
     constexpr int WBUF = 2 * 3 * 2 * VF_COLS;                      // u32x4 per stage buffer
@@ -110,33 +110,44 @@ __global__ __launch_bounds__(VF_NT) void vit_qkv_attn_kernel(VitDesc d) {
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
+    // weights: global loads three stages ahead (two register sets), LDS two stages ahead (three buffers), so a stage's
+    // first fragment can be read before the barrier that ends the previous stage; tokens: two register sets
     load_w(0, S0{});
-    load_a(0, S0{});
     load_w(1, S1{});
+    load_a(0, S0{});
     load_a(1, S1{});
     store_w(W0, S0{});
+    load_w(2, S0{});
+    store_w(W0 + WBUF, S1{});
     __syncthreads();
-    // stage s: weights in LDS buffer s & 1; its tokens and the NEXT stage's weights sit in register set s & 1 / (s+1) & 1
+    u32x4 bf[2][3];
+    auto read_b = [&](u32x4 (&dst)[3], const u32x4* buf, int t, int c) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p] = buf[((t * 3 + p) * 2 + lh) * VF_COLS + (3 * wcol + c) * 32 + l31];
+    };
+    read_b(bf[0], W0, 0, 0);
+    int rb = 0, wb = 2;
     auto stage = [&](int s, auto cur_tag) {
         constexpr int CUR = decltype(cur_tag)::value;
-        const u32x4* cur = W0 + CUR * WBUF;
+        const u32x4* cur = W0 + rb * WBUF;
+        rb = rb == 2 ? 0 : rb + 1;
+        const u32x4* nxt = W0 + rb * WBUF;
         u32x4 a[2][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t) split3x8(araw3[CUR][t], a[t][0], a[t][1], a[t][2]);
-        load_a(s + 2, cur_tag);                                   // (set CUR is free again: just split)
-        load_w(s + 2, cur_tag);                                   // (its weights went to LDS a stage ago)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                u32x4 b[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) b[p] = cur[((t * 3 + p) * 2 + lh) * VF_COLS + (3 * wcol + c) * 32 + l31];
-                acc[c] = mfma_split(a[t], b, acc[c]);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        store_w(W0 + (CUR ^ 1) * WBUF, std::integral_constant<int, CUR ^ 1>{});     // stage s+1, loaded a stage ago
+        load_a(s + 2, cur_tag);                                        // (set CUR is free again: just split)
+        load_w(s + 3, std::integral_constant<int, CUR ^ 1>{});        // (set CUR^1 went to LDS a stage ago)
+        static_for<6>([&](auto g_tag) {
+            constexpr int G = decltype(g_tag)::value, t = G / 3, c = G % 3;
+            constexpr int fcur = G & 1, fnxt = fcur ^ 1;
+            if constexpr (G < 5) read_b(bf[fnxt], cur, (G + 1) / 3, (G + 1) % 3);
+            else read_b(bf[fnxt], nxt, 0, 0);                          // published one barrier ago
+            __builtin_amdgcn_sched_barrier(0);
+            acc[c] = mfma_split(a[t], bf[fcur], acc[c]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        store_w(W0 + wb * WBUF, cur_tag);                              // stage s + 2 (loaded two stages ago)
+        wb = wb == 2 ? 0 : wb + 1;
         __syncthreads();
     };
     for (int s = 0; s < nstage; s += 2) {
@@ -230,8 +241,8 @@ extern "C" int scat_vit_qkv_attn_fwd(const float* h, const float* wqkv, float* q
     d.nh = (int64_t)B * n * dim;
     d.nw = ((int64_t)((dim + 15) / 16) * 3 * 3 * inner * 32 + 3) / 4;
     const int nblk = cdiv(B, d.IB);
-    constexpr size_t lds_bytes = sizeof(float) * (128 * VF_TS + 6 * 32 * 33);     // tile + scores (>= 2 weight buffers)
-    static_assert(lds_bytes >= (size_t)2 * 2 * 3 * 2 * VF_COLS * 16, "weight buffers fit under the tile");
+    constexpr size_t lds_bytes = sizeof(float) * (128 * VF_TS + 6 * 32 * 33);     // tile + scores (>= 3 weight buffers)
+    static_assert(lds_bytes >= (size_t)3 * 2 * 3 * 2 * VF_COLS * 16, "weight buffers fit under the tile");
     static bool once = (hipFuncSetAttribute((const void*)vit_qkv_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes) == hipSuccess);
     (void)once;
