@@ -36,8 +36,12 @@ constexpr int VF_TS = VF_COLS + 1;           // padded row of the parked project
 
 // 512 threads: wavefronts 0-3 own columns 0..95 of their 32 token rows, wavefronts 4-7 columns 96..191 (two wavefronts
 // per SIMD: one's fragment reads and waits are covered by the other's MFMAs)
-constexpr int VF_NT = 512, VF_NI = 9 * 256 / VF_NT + 1;      // staging items per thread (2304 per stage)
-__global__ __launch_bounds__(VF_NT) void vit_qkv_attn_kernel(VitDesc d) {
+// RW = token rows per workgroup (128: six 21-token images, 64: three).  Threads = 2 x (RW / 32) wavefronts: one per
+// (32-row block, column half).  64-row blocks give 32 x 8 = 256 workgroups at batch 96 — every CU one — at the price of
+// reading each head's weight slice twice as often.
+template <int RW>
+__global__ __launch_bounds__(RW * 4) void vit_qkv_attn_kernel(VitDesc d) {
+    constexpr int VF_NT = RW * 4, VF_NI = (2304 + VF_NT - 1) / VF_NT;     // staging items per thread (2304 per stage)
     extern __shared__ __align__(16) float lds[];
     // during the projection: three weight stage buffers [2 chunks][3 planes][2 k-octets][192 cols] x 16 B = 36,864 B each;
     // afterwards the same memory holds the projection tile [128][193] floats and the scores [IB][n][n + 1]
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(VF_NT) void vit_qkv_attn_kernel(VitDesc d) {
     constexpr int WBUF = 2 * 3 * 2 * VF_COLS;                      // u32x4 per stage buffer
     const int head = blockIdx.x % d.heads, blk = blockIdx.x / d.heads;
     const int inner = d.heads * 64, ld = 3 * inner;
-    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wcol = tid >> 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % (RW / 32), wcol = (tid >> 6) / (RW / 32);
     const int l31 = lane & 31, lh = lane >> 5;
     const int rows_blk = d.IB * d.n;
     const int r0 = blk * rows_blk;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(VF_NT) void vit_qkv_attn_kernel(VitDesc d) {
 
     // ---- park the projection tile in LDS (the weight buffers are dead) and write qkv
     float* const T = lds;                                   // [128][VF_TS]
-    float* const S = lds + 128 * VF_TS;                     // [IB][n][n + 1]
+    float* const S = lds + RW * VF_TS;                      // [IB][n][n + 1]
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -237,17 +241,28 @@ extern "C" int scat_vit_qkv_attn_fwd(const float* h, const float* wqkv, float* q
     wprep_launch(wprep_job(wqkv, ws, 3 * inner, dim, 0, 1, 1, 1, 1, 0, 0, 1), st);
     VitDesc d{};
     d.h = h; d.wq = (const float*)ws; d.qkv = qkv; d.attn = attn; d.ao = ao;
-    d.B = B; d.n = n; d.dim = dim; d.heads = heads; d.Mtok = B * n; d.IB = 128 / n; d.scale = scale;
+    // 64-row blocks when 128-row ones would leave CUs without a workgroup
+    const bool small = n <= 64 && (int64_t)cdiv(B, 128 / n) * heads < 200 && B > 128 / n;
+    const int RW = small ? 64 : 128;
+    d.B = B; d.n = n; d.dim = dim; d.heads = heads; d.Mtok = B * n; d.IB = RW / n; d.scale = scale;
     d.nh = (int64_t)B * n * dim;
     d.nw = ((int64_t)((dim + 15) / 16) * 3 * 3 * inner * 32 + 3) / 4;
     const int nblk = cdiv(B, d.IB);
-    constexpr size_t lds_bytes = sizeof(float) * (128 * VF_TS + 6 * 32 * 33);     // tile + scores (>= 3 weight buffers)
-    static_assert(lds_bytes >= (size_t)3 * 2 * 3 * 2 * VF_COLS * 16, "weight buffers fit under the tile");
-    static bool once = (hipFuncSetAttribute((const void*)vit_qkv_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds_bytes) == hipSuccess);
-    (void)once;
-    set_kernel_label("vit_qkv_attn_fused_128x192x32");
-    hipLaunchKernelGGL(vit_qkv_attn_kernel, dim3(nblk * heads), dim3(VF_NT), lds_bytes, st, d);
+    // LDS: max(three weight stage buffers, projection tile + scores)
+    constexpr size_t wbytes = (size_t)3 * 2 * 3 * 2 * VF_COLS * 16;
+    auto launch = [&](auto rw_tag) {
+        constexpr int R = decltype(rw_tag)::value;
+        constexpr size_t tbytes = sizeof(float) * (R * VF_TS + R * 33);
+        constexpr size_t lds_bytes = tbytes > wbytes ? tbytes : wbytes;
+        auto kern = vit_qkv_attn_kernel<R>;
+        static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)lds_bytes) == hipSuccess);
+        (void)once;
+        hipLaunchKernelGGL(kern, dim3(nblk * heads), dim3(R * 4), lds_bytes, st, d);
+    };
+    set_kernel_label("vit_qkv_attn_fused_%dx192x32", RW);
+    if (small) launch(std::integral_constant<int, 64>{});
+    else launch(std::integral_constant<int, 128>{});
     SCAT_LAUNCH_CHECK("scat_vit_qkv_attn_fwd");
     return SCAT_OK;
 }

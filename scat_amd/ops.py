@@ -580,9 +580,10 @@ def attention_fwd(qkv, heads, dim_head, scale):
 
 
 # qkv projection + attention of a layer in one launch (csrc/vit_fused.hip).  Off by default: measured at batch 96
-# (tools/vit_fused_bench.py) the fused launch takes 87-97 / 59-63 / 42-46 us for dim 784 / 392 / 196 against 73 / 51 / 36 us
-# for the two launches it replaces — 128 workgroups of 21-row images cannot feed the matrix pipe better than the
-# engine's 64x64 tiles do, and the step time does not move (the token path hides under layer3/layer4).
+# (tools/vit_fused_bench.py, profiles/r02_vit_fused.txt) the fused launch takes 77 / 51 / 38 us for dim 784 / 392 / 196
+# against 74 / 51 / 36 us for the two launches it replaces — 256 workgroups of three 21-token images each stream their
+# head's weight slice at the per-CU L2 fetch rate (~25 GB/s: 2.2 us per 32-feature stage for 0.6 us of MFMA), and the
+# step time does not move (the token path hides under layer3/layer4).
 VIT_FUSED = os.environ.get("SCAT_VIT_FUSED", "0") != "0"
 
 
