@@ -353,6 +353,9 @@ def init_distributed():
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run)."""
     import os
 
+    # the host driver of this pool only supports dmabuf IPC: RCCL's peer mappings over xGMI fail with
+    # "hipIpcGetMemHandle: invalid argument" without it (must be in the environment before HIP initialises)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
