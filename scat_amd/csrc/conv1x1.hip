@@ -510,9 +510,11 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
 // 4-byte ones, LDS writes of 8 bytes that consecutive lanes place in consecutive slots — and a consumer lane's four
 // accumulator columns are four consecutive pixels of one row: the epilogue stores 16 bytes per instruction instead of
 // 4.  The MFMA does not care which pixel a column is; only the two ends of the kernel know.
-template <int MI, bool TF, int DIAG = 0, bool W4 = false>
-__global__ __launch_bounds__(512, (MI == 1 ? 4 : 2)) void conv1x1_pc_kernel(PwDesc d, OutDesc dc) {
-    constexpr int BN = 128, BM = 128 * MI, NI = 4, PT = 256;
+// NCW consumer wavefronts (32 MI rows each) + 4 producers.  NCW = 8: a 256 x 128 tile staged once for twice the rows —
+// half the activation traffic and producer work per MFMA, two consumers per SIMD inside ONE workgroup per CU.
+template <int MI, bool TF, int DIAG = 0, bool W4 = false, int NCW = 4>
+__global__ __launch_bounds__((NCW + 4) * 64, (NCW == 8 ? 3 : (MI == 1 ? 4 : 2))) void conv1x1_pc_kernel(PwDesc d, OutDesc dc) {
+    constexpr int BN = 128, BM = 32 * NCW * MI, NI = 4, PT = 256;
     constexpr int NIT = 4 * BN / PT;                  // k-octets per producer thread per 32-channel stage
     constexpr int BUF = 12 * BN;                      // u32x4 per buffer: [3 planes][4 k-octets][BN]
     extern __shared__ __align__(16) float lds[];
@@ -529,13 +531,13 @@ __global__ __launch_bounds__(512, (MI == 1 ? 4 : 2)) void conv1x1_pc_kernel(PwDe
     using S1 = std::integral_constant<int, 1>;
 
     if constexpr (W4) {
-      if (wave >= 4) {
+      if (wave >= NCW) {
         // ------------------------------------------------------------ producer, wide form: wavefront = k-octet,
         // lane = (pixel quad p, channel half h)
         const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(d.src, d.nsrc);
         const __amdgpu_buffer_rsrc_t rsrc_sc = make_rsrc(TF ? d.scale : d.src, TF ? d.C : 0);
         const __amdgpu_buffer_rsrc_t rsrc_sh = make_rsrc(TF ? d.shift : d.src, TF ? d.C : 0);
-        const int g = wave - 4, p = lane >> 1, h = lane & 1;
+        const int g = wave - NCW, p = lane >> 1, h = lane & 1;
         const int chw4 = d.HW * 4;
         int boff;                                      // byte offset of (image, channel 8g + 4h, first pixel of the quad)
         {
@@ -613,9 +615,9 @@ __global__ __launch_bounds__(512, (MI == 1 ? 4 : 2)) void conv1x1_pc_kernel(PwDe
         return;
       }
     } else
-    if (wave >= 4) {
+    if (wave >= NCW) {
         // ------------------------------------------------------------ producer
-        const int ptid = threadIdx.x - 256;
+        const int ptid = threadIdx.x - 64 * NCW;
         const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(d.src, d.nsrc);
         const int pcol = ptid % BN, g0 = ptid / BN;
         const int g0u = __builtin_amdgcn_readfirstlane(g0);
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(512, (MI == 1 ? 4 : 2)) void conv1x1_pc_kernel(PwDe
             }
         return;
     }
-    store_tile<MI, NI, BM, BN, 4, 1>(acc, dc, d.M, d.npix, i0, j0, 0);
+    store_tile<MI, NI, BM, BN, NCW, 1>(acc, dc, d.M, d.npix, i0, j0, 0);
 }
 
 // ws[tap][ch][plane][i][16 bf16]: the three bf16 terms of element (i, c, tap).  w is the conv weight
@@ -909,24 +911,25 @@ __global__ __launch_bounds__(256) void stem_wprep_kernel(const float* __restrict
     }
 }
 
-// SCAT_PC: 0 = every wavefront stages and multiplies (conv1x1_split_kernel), 1 = producer/consumer wavefronts with
+// SCAT_PC: unset = per-layer choice (see scat_conv1x1_s1), 0 = every wavefront stages and multiplies
+// (conv1x1_split_kernel), 5 / 6 = eight consumer wavefronts on a 256 x 128 tile (plain / wide form), 1 = producer/consumer wavefronts with
 // 128-row tiles, 2 = 256-row tiles where the layer has them, 3 / 4 = the same with the wide (pixel-quad) form where the
 // plane allows it
 static int pc_mode() {
-    static const int m = [] { const char* e = getenv("SCAT_PC"); return e ? atoi(e) : 0; }();
+    static const int m = [] { const char* e = getenv("SCAT_PC"); return e ? atoi(e) : -1; }();
     return m;
 }
 
-template <int MI, bool TF, int DIAG = 0, bool W4 = false>
+template <int MI, bool TF, int DIAG = 0, bool W4 = false, int NCW = 4>
 static void launch_pw_pc(const PwDesc& d, const OutDesc& dc, hipStream_t st) {
-    constexpr int BM = 128 * MI, BN = 128;
+    constexpr int BM = 32 * NCW * MI, BN = 128;
     const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, BN);
     constexpr size_t lds_bytes = (size_t)3 * 12 * BN * 16;
-    auto kern = conv1x1_pc_kernel<MI, TF, DIAG, W4>;
+    auto kern = conv1x1_pc_kernel<MI, TF, DIAG, W4, NCW>;
     static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes) == hipSuccess);
     (void)once;
-    hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(512), lds_bytes, st, d, dc);
+    hipLaunchKernelGGL(kern, dim3(mt * nt), dim3((NCW + 4) * 64), lds_bytes, st, d, dc);
 }
 
 template <int BM, int BN, bool V4, bool TF>
@@ -1138,10 +1141,27 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
             cfg = M > 64 ? 0 : 1;   // measured at batch 96: 64x64 never wins
             if (cfg == 0 && tiles(128, 128) < thin) cfg = 1;          // (SCAT_PW_THIN: 64x128 below that many tiles)
         }
-        const int pc = pc_mode();
+        int pc = pc_mode();
+        // default (SCAT_PC unset): the 8-consumer producer/consumer form for the few layers whose 128x128 tile count is
+        // just over one tile per CU (294-296 tiles at batch 96: 1024->256 @14x14 forward, 256->1024 @14x14 and
+        // 1024->2048 @7x7 data gradients) — there the round-1 kernel runs 38 CUs with two workgroups and 218 with one,
+        // and one 256x128 workgroup per CU is 10-15 % faster (profiles/r02_conv_shapes.txt); everywhere else the
+        // round-1 form wins.  The 64-wide tile counts are batch dependent, the rule is not.
+        if (pc < 0) pc = (cfg == 0 && M >= 256 && tiles(128, 128) >= 257 && tiles(128, 128) < 330) ? 6 : 0;
         // wide form: pointwise, whole pixel quads inside one image, 16-byte aligned planes, NCHW output
         const bool w4ok = HW % 4 == 0 && ((uintptr_t)dst & 15) == 0 && (!bias || dc.bias_mode == 1);
-        if (cfg == 0 && pc >= 3 && w4ok) {
+        if (cfg == 0 && (pc == 5 || pc == 6) && M >= 256) {
+            const bool wide = pc == 6 && w4ok;
+            set_kernel_label("conv1x1_split_pc%s256x128x32%s", wide ? "4_" : "8w_", in_scale ? "_tf" : "");
+            if (wide) {
+                if (in_scale) launch_pw_pc<1, true, 0, true, 8>(d, dc, st); else launch_pw_pc<1, false, 0, true, 8>(d, dc, st);
+            } else {
+                if (in_scale) launch_pw_pc<1, true, 0, false, 8>(d, dc, st); else launch_pw_pc<1, false, 0, false, 8>(d, dc, st);
+            }
+            SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
+            return SCAT_OK;
+        }
+        if (cfg == 0 && pc >= 3 && pc <= 4 && w4ok) {
             const bool big = pc == 4 && M >= 256;
             set_kernel_label("conv1x1_split_pc4_%dx128x32%s", big ? 256 : 128, in_scale ? "_tf" : "");
             if (!in_scale && !big && tuning() >= 100) {
@@ -1162,7 +1182,7 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
             SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
             return SCAT_OK;
         }
-        if (cfg == 0 && pc) {
+        if (cfg == 0 && pc && pc <= 4) {
             const bool big = (pc == 2 || pc == 4) && M >= 256;
             set_kernel_label("conv1x1_split_pc%dx128x32%s", big ? 256 : 128, in_scale ? "_tf" : "");
             if (!in_scale && !big && tuning() >= 100) {      // timing experiments (SCAT_TUNE=100+DIAG)
