@@ -818,29 +818,38 @@ __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 8 ? 3 : (MI == 1 ? 4 : 2)))
 // ws[tap][ch][plane][i][16 bf16]: the three bf16 terms of element (i, c, tap).  w is the conv weight
 // [Cout][Cin][KH][KW]; forward: (i, c) = (co, ci); transposed (data gradient): (i, c) = (ci, co).  Tap t of the ntap
 // listed ones is (kh0 + ts*(t / KWt), kw0 + ts*(t % KWt)).  (WPrepJob in conv_common.h.)
-__device__ __forceinline__ void wprep_element(const WPrepJob& j, int64_t e) {
+// One work item = one k-octet of one row: 8 source weights -> three 16-byte stores (hi | mid | lo planes), the stores of
+// a wavefront contiguous (item index = (r, i, half) with half fastest).  The first version made one element per thread
+// with three 2-byte stores: 207 us per step for the 106 convolutions of ResNet-50 against ~60 us of HBM time.
+__device__ __forceinline__ void wprep_octet(const WPrepJob& j, int64_t e) {
     const int nchunk = (j.C + 15) / 16;
-    const int k16 = e & 15;
-    int64_t r = e >> 4;
+    const int half = e & 1;
+    int64_t r = e >> 1;
     const int i = r % j.M;
     r /= j.M;                                            // r = tap * nchunk + ch
     const int ch = r % nchunk, t = r / nchunk;
-    const int c = ch * 16 + k16;
     const int kh = j.kh0 + j.ts * (t / j.KWt), kw = j.kw0 + j.ts * (t % j.KWt);
-    const int64_t pair = j.transposed ? (int64_t)c * j.M + i : (int64_t)i * j.C + c;
-    const float v = c < j.C ? j.w[(pair * j.KH + kh) * j.KW + kw] : 0.f;
-    uint32_t hi, mid, lo;
-    split3(v, 0.f, hi, mid, lo);
-    const int64_t base = (r * 3 * j.M + i) * 16 + k16;
-    j.dst[base] = (uint16_t)hi;
-    j.dst[base + (int64_t)j.M * 16] = (uint16_t)mid;
-    j.dst[base + (int64_t)2 * j.M * 16] = (uint16_t)lo;
+    const int c0 = ch * 16 + half * 8;
+    const int64_t tap = (int64_t)kh * j.KW + kw, kk = (int64_t)j.KH * j.KW;
+    float v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int c = c0 + m;
+        const int64_t pair = j.transposed ? (int64_t)c * j.M + i : (int64_t)i * j.C + c;
+        v[m] = c < j.C ? j.w[pair * kk + tap] : 0.f;
+    }
+    u32x4 hi, mid, lo;
+    split3x8(v, hi, mid, lo);
+    u32x4* dst = (u32x4*)j.dst + ((r * 3) * j.M + i) * 2 + half;      // 16-byte units
+    dst[0] = hi;
+    dst[(int64_t)j.M * 2] = mid;
+    dst[(int64_t)j.M * 4] = lo;
 }
-static inline int64_t wprep_elements(const WPrepJob& j) { return (int64_t)j.ntap * ((j.C + 15) / 16) * j.M * 16; }
+static inline int64_t wprep_elements(const WPrepJob& j) { return (int64_t)j.ntap * ((j.C + 15) / 16) * j.M * 2; }
 
 __global__ __launch_bounds__(256) void w_taps_split_kernel(WPrepJob j) {
-    const int64_t n = (int64_t)j.ntap * ((j.C + 15) / 16) * j.M * 16;
-    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n; e += gridDim.x * 256ll) wprep_element(j, e);
+    const int64_t n = (int64_t)j.ntap * ((j.C + 15) / 16) * j.M * 2;
+    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n; e += gridDim.x * 256ll) wprep_octet(j, e);
 }
 
 // the same for a table of jobs (device memory, sorted by blk0): block b belongs to the last job with blk0 <= b
@@ -853,9 +862,9 @@ __global__ __launch_bounds__(256) void w_prep_batch_kernel(const WPrepJob* __res
         else hi = mid - 1;
     }
     const WPrepJob j = jobs[lo];
-    const int64_t n = (int64_t)j.ntap * ((j.C + 15) / 16) * j.M * 16;
+    const int64_t n = (int64_t)j.ntap * ((j.C + 15) / 16) * j.M * 2;
     const int64_t e = (int64_t)(b - j.blk0) * 256 + threadIdx.x;
-    if (e < n) wprep_element(j, e);
+    if (e < n) wprep_octet(j, e);
 }
 
 WPrepJob wprep_job(const float* w, void* dst, int M, int C, int transposed, int KH, int KW, int ntap, int KWt, int kh0,
