@@ -512,7 +512,10 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
 // 4.  The MFMA does not care which pixel a column is; only the two ends of the kernel know.
 // NCW consumer wavefronts (32 MI rows each) + 4 producers.  NCW = 8: a 256 x 128 tile staged once for twice the rows —
 // half the activation traffic and producer work per MFMA, two consumers per SIMD inside ONE workgroup per CU.
-template <int MI, bool TF, int DIAG = 0, bool W4 = false, int NCW = 4>
+// S16: the consumers issue v_mfma_f32_16x16x32_bf16 (a whole 32-channel stage per instruction, 16 x 16 tiles) instead of
+// 32x32x16: the same fragments, planes and LDS image, addressed as lane (l & 15, k-octet l >> 4); the chip holds a
+// higher clock on this shape (tools/mfma_probe.hip: +5 % with the LDS reads).
+template <int MI, bool TF, int DIAG = 0, bool W4 = false, int NCW = 4, bool S16 = false>
 __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 8 ? 3 : (MI == 1 ? 4 : 2))) void conv1x1_pc_kernel(PwDesc d, OutDesc dc) {
     constexpr int BN = 128, BM = 32 * NCW * MI, NI = 4, PT = 256;
     constexpr int NIT = 4 * BN / PT;                  // k-octets per producer thread per 32-channel stage
@@ -715,6 +718,101 @@ __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 8 ? 3 : (MI == 1 ? 4 : 2)))
         return;
     }
 
+    if constexpr (S16) {
+        // ------------------------------------------------------------ consumer, 16x16x32 form (MI = 1, plain columns)
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        const int l15 = lane & 15, kq = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(d.w, d.nw);
+        const int aplane = d.M * 32;
+        const int nchunk = (d.C + 15) / 16;
+        int aoff[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int row = i0 + wave * 32 + rb * 16 + l15;
+            aoff[rb] = row < d.M ? row * 32 + (kq & 1) * 16 + (kq >> 1) * 3 * aplane : OOB;
+        }
+        auto load_a = [&](u32x4 (&dst)[3], int st, int rb) {     // the 16 rows rb of stage st: 32 channels per lane group
+            const int tap = st / nsc, ch = (st - tap * nsc) * 2;
+            const bool ok = st < nstage && ch + (kq >> 1) < nchunk;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                dst[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? aoff[rb] : OOB,
+                                                               ((tap * nchunk + ch) * 3 + p) * aplane, 0);
+        };
+        f32x4v acc[2][8];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) acc[rb][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        const int b_frag = kq * BN + l15;
+        auto read_b = [&](u32x4 (&dst)[3], const u32x4* buf, int cb) {
+            const u32x4* p = buf + b_frag + cb * 16;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) dst[q] = p[q * 4 * BN];
+        };
+        auto mfma6 = [&](const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4v c) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0]), am = __builtin_bit_cast(bf16x8, a[1]),
+                         al = __builtin_bit_cast(bf16x8, a[2]);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, b[0]), bm = __builtin_bit_cast(bf16x8, b[1]),
+                         bl = __builtin_bit_cast(bf16x8, b[2]);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+            return c;
+        };
+        // the two 16-row halves of a stage run one after the other (fragments re-read per half: 48 reads per stage),
+        // so a half's weights are dead after its 8 column blocks and the next stage's load over them has half a stage
+        // of cover: one register set per half
+        u32x4 areg[2][3];
+        u32x4 bfr[2][3];
+        load_a(areg[0], 0, 0);
+        load_a(areg[1], 0, 1);
+        __syncthreads();
+        read_b(bfr[0], B0, 0);
+        int rb_ = 0;
+        for (int s = 0; s < nstage; ++s) {
+            const u32x4* bcur = B0 + rb_ * BUF;
+            rb_ = rb_ == 2 ? 0 : rb_ + 1;
+            const u32x4* bnxt = B0 + rb_ * BUF;
+            static_for<16>([&](auto i_tag) {
+                constexpr int I = decltype(i_tag)::value, rb = I / 8, cb = I % 8;
+                constexpr int fcur = I & 1, fnxt = fcur ^ 1;
+                if constexpr (I == 8) load_a(areg[0], s + 1, 0);       // half 0 is done with its weights
+                if constexpr (I < 15) read_b(bfr[fnxt], bcur, (I + 1) % 8);
+                else read_b(bfr[fnxt], bnxt, 0);                        // published one barrier ago
+                __builtin_amdgcn_sched_barrier(0);
+                acc[rb][cb] = mfma6(areg[rb], bfr[fcur], acc[rb][cb]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            load_a(areg[1], s + 1, 1);
+            __syncthreads();
+        }
+        // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+        const __amdgpu_buffer_rsrc_t rc = make_rsrc(dc.p, dc.n);
+        const bool biasi = dc.bias && dc.bias_mode == 1;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) {
+            const int j = j0 + cb * 16 + l15;
+            const bool colok = j < d.npix;
+            const uint32_t jj = colok ? (uint32_t)j : 0u;
+            const uint32_t n = dc.dHW.div(jj);
+            const int coloff = (int)n * dc.C * dc.HW + (int)(jj - n * (uint32_t)dc.HW);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + wave * 32 + rb * 16 + kq * 4 + r;
+                    const int vo = (colok && i < d.M) ? (coloff + i * dc.HW) * 4 : OOB;
+                    float v = acc[rb][cb][r] + (biasi ? dc.bias[i < d.M ? i : 0] : 0.f);
+                    if (dc.accumulate) v += bload(rc, vo);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, vo, 0, 0);
+                }
+        }
+        return;
+    }
     // ---------------------------------------------------------------- consumer: rows i0 + wave*32*MI ..
     const int l31 = lane & 31, lh = lane >> 5;
     const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(d.w, d.nw);
@@ -929,12 +1027,12 @@ static int pc_mode() {
     return m;
 }
 
-template <int MI, bool TF, int DIAG = 0, bool W4 = false, int NCW = 4>
+template <int MI, bool TF, int DIAG = 0, bool W4 = false, int NCW = 4, bool S16 = false>
 static void launch_pw_pc(const PwDesc& d, const OutDesc& dc, hipStream_t st) {
     constexpr int BM = 32 * NCW * MI, BN = 128;
     const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, BN);
     constexpr size_t lds_bytes = (size_t)3 * 12 * BN * 16;
-    auto kern = conv1x1_pc_kernel<MI, TF, DIAG, W4, NCW>;
+    auto kern = conv1x1_pc_kernel<MI, TF, DIAG, W4, NCW, S16>;
     static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes) == hipSuccess);
     (void)once;
@@ -1159,6 +1257,13 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
         if (pc < 0) pc = (cfg == 0 && M >= 256 && tiles(128, 128) >= 257 && tiles(128, 128) < 330) ? 6 : 0;
         // wide form: pointwise, whole pixel quads inside one image, 16-byte aligned planes, NCHW output
         const bool w4ok = HW % 4 == 0 && ((uintptr_t)dst & 15) == 0 && (!bias || dc.bias_mode == 1);
+        if (cfg == 0 && pc == 7 && dc.mode == 1 && (!bias || dc.bias_mode == 1)) {
+            set_kernel_label("conv1x1_split_pc16_128x128x32%s", in_scale ? "_tf" : "");
+            if (in_scale) launch_pw_pc<1, true, 0, false, 4, true>(d, dc, st);
+            else launch_pw_pc<1, false, 0, false, 4, true>(d, dc, st);
+            SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
+            return SCAT_OK;
+        }
         if (cfg == 0 && (pc == 5 || pc == 6) && M >= 256) {
             const bool wide = pc == 6 && w4ok;
             set_kernel_label("conv1x1_split_pc%s256x128x32%s", wide ? "4_" : "8w_", in_scale ? "_tf" : "");
