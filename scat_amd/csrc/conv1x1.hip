@@ -515,13 +515,41 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
 // S16: the consumers issue v_mfma_f32_16x16x32_bf16 (a whole 32-channel stage per instruction, 16 x 16 tiles) instead of
 // 32x32x16: the same fragments, planes and LDS image, addressed as lane (l & 15, k-octet l >> 4); the chip holds a
 // higher clock on this shape (tools/mfma_probe.hip: +5 % with the LDS reads).
-template <int MI, bool TF, int DIAG = 0, bool W4 = false, int NCW = 4, bool S16 = false>
+// RING = R > 0: no workgroup barrier in the main loop.  The stage buffers form a ring of R slots with two LDS words per
+// slot: FULL (each of the 4 producer wavefronts adds 1 once its part of the stage is written) and FREE (each of the NCW
+// consumers adds 1 once it has read the stage).  A producer runs ahead until the ring is full, a consumer waits only for
+// data that is not there: the two streams are coupled by data, not by a rendezvous every stage (with a barrier per
+// stage, a late load stalls the MFMA wavefronts even when the fragments they need next are already in LDS).  Spins are
+// bounded (the kernel ends with wrong results rather than hanging should a count be wrong).
+template <int MI, bool TF, int DIAG = 0, bool W4 = false, int NCW = 4, bool S16 = false, int RING = 0>
 __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 8 ? 3 : (MI == 1 ? 4 : 2))) void conv1x1_pc_kernel(PwDesc d, OutDesc dc) {
     constexpr int BN = 128, BM = 32 * NCW * MI, NI = 4, PT = 256;
+    static_assert(RING == 0 || (!W4 && !S16 && RING >= 3), "ring form: plain columns, 32x32x16");
     constexpr int NIT = 4 * BN / PT;                  // k-octets per producer thread per 32-channel stage
     constexpr int BUF = 12 * BN;                      // u32x4 per buffer: [3 planes][4 k-octets][BN]
     extern __shared__ __align__(16) float lds[];
     u32x4* const B0 = (u32x4*)lds;
+    // ring form: FULL[R] | FREE[R] behind the R stage buffers
+    unsigned* const ring_full = (unsigned*)(B0 + (RING > 0 ? RING : 3) * BUF);
+    unsigned* const ring_free = ring_full + (RING > 0 ? RING : 0);
+    if constexpr (RING > 0) {
+        if (threadIdx.x < 2 * RING) ring_full[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    // (relaxed LDS accesses + compiler barriers: the LDS serves one wavefront's requests in order, so "writes, then
+    // lgkmcnt(0), then the count" and "poll, then reads" need no hardware fence; a release/acquire pair would make hipcc
+    // drain vmcnt too and with it the producers' prefetched global loads)
+    auto wait_ge = [&](unsigned* p, unsigned target) {
+        for (int it = 0; it < (1 << 16); ++it) {
+            if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto signal = [&](unsigned* p) {
+        asm volatile("" ::: "memory");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
 
     const int mt = (d.M + BM - 1) / BM, nt = (d.npix + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, mt * nt);
@@ -697,6 +725,24 @@ __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 8 ? 3 : (MI == 1 ? 4 : 2)))
                 dst[(2 * 4 + g) * BN + pcol] = lo;
             }
         };
+        if constexpr (RING > 0) {
+            load_b(0, S0{});
+            load_b(1, S1{});
+            int slot = 0, use = 0;
+            auto put = [&](int ps, auto par_tag) {
+                if (use > 0) wait_ge(ring_free + slot, (unsigned)(NCW * use));     // every consumer has read its last use
+                store_b(ps, B0 + slot * BUF, par_tag);
+                load_b(ps + 2, par_tag);                                           // (the set is free again)
+                __builtin_amdgcn_s_waitcnt(0xc07f);                                // lgkmcnt(0): the writes have landed
+                signal(ring_full + slot);
+                if (++slot == RING) { slot = 0; ++use; }
+            };
+            for (int ps = 0; ps < nstage; ps += 2) {
+                put(ps, S0{});
+                if (ps + 1 < nstage) put(ps + 1, S1{});
+            }
+            return;
+        }
         load_b(0, S0{});
         load_b(1, S1{});
         store_b(0, B0, S0{});
@@ -853,17 +899,23 @@ __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 8 ? 3 : (MI == 1 ? 4 : 2)))
     u32x4 areg[2][MI][3];
     u32x4 bfr[2][3];
     load_a(areg[0], 0);
-    __syncthreads();
+    if constexpr (RING > 0) wait_ge(ring_full, 4u);
+    else __syncthreads();
     read_b(bfr[0], B0, 0, 0);
-    int rb = 0;
+    int rb = 0, ruse = 0;
+    constexpr int NSLOT = RING > 0 ? RING : 3;
     for (int s = 0; s < nstage; ++s) {
         const u32x4* bcur = B0 + rb * BUF;
-        rb = rb == 2 ? 0 : rb + 1;
+        unsigned* const fcur_free = ring_free + rb;
+        if (++rb == NSLOT) { rb = 0; ++ruse; }
         const u32x4* bnxt = B0 + rb * BUF;
         static_for<2 * NI>([&](auto i_tag) {
             constexpr int I = decltype(i_tag)::value, t = I / NI, b = I % NI;
             if constexpr (b == 0) load_a(areg[t ^ 1], 2 * s + t + 1);
             constexpr int fcur = I & 1, fnxt = fcur ^ 1;
+            if constexpr (RING > 0 && I == 2 * NI - 1) {
+                if (s + 1 < nstage) wait_ge(ring_full + rb, 4u * (unsigned)(ruse + 1));      // the next stage is in LDS
+            }
             if constexpr (b + 1 < NI) read_b(bfr[fnxt], bcur, t, b + 1);
             else if constexpr (t == 0) read_b(bfr[fnxt], bcur, 1, 0);
             else read_b(bfr[fnxt], bnxt, 0, 0);          // published one barrier ago
@@ -881,7 +933,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 8 ? 3 : (MI == 1 ? 4 : 2)))
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        __syncthreads();
+        if constexpr (RING > 0) signal(fcur_free);       // (LDS serves a wavefront's requests in order: its reads of
+        else __syncthreads();                             //  this slot are behind it)
     }
     if constexpr (DIAG & 8) {
         if (d.variant != 0x7fffffff) return;          // (never true: keeps the accumulators live)
@@ -1027,12 +1080,12 @@ static int pc_mode() {
     return m;
 }
 
-template <int MI, bool TF, int DIAG = 0, bool W4 = false, int NCW = 4, bool S16 = false>
+template <int MI, bool TF, int DIAG = 0, bool W4 = false, int NCW = 4, bool S16 = false, int RING = 0>
 static void launch_pw_pc(const PwDesc& d, const OutDesc& dc, hipStream_t st) {
     constexpr int BM = 32 * NCW * MI, BN = 128;
     const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, BN);
-    constexpr size_t lds_bytes = (size_t)3 * 12 * BN * 16;
-    auto kern = conv1x1_pc_kernel<MI, TF, DIAG, W4, NCW, S16>;
+    constexpr size_t lds_bytes = (size_t)(RING > 0 ? RING : 3) * 12 * BN * 16 + (RING > 0 ? 64 : 0);
+    auto kern = conv1x1_pc_kernel<MI, TF, DIAG, W4, NCW, S16, RING>;
     static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes) == hipSuccess);
     (void)once;
@@ -1257,6 +1310,13 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
         if (pc < 0) pc = (cfg == 0 && M >= 256 && tiles(128, 128) >= 257 && tiles(128, 128) < 330) ? 6 : 0;
         // wide form: pointwise, whole pixel quads inside one image, 16-byte aligned planes, NCHW output
         const bool w4ok = HW % 4 == 0 && ((uintptr_t)dst & 15) == 0 && (!bias || dc.bias_mode == 1);
+        if (cfg == 0 && pc == 8 && M >= 256) {
+            set_kernel_label("conv1x1_split_pcring_256x128x32%s", in_scale ? "_tf" : "");
+            if (in_scale) launch_pw_pc<1, true, 0, false, 8, false, 6>(d, dc, st);
+            else launch_pw_pc<1, false, 0, false, 8, false, 6>(d, dc, st);
+            SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
+            return SCAT_OK;
+        }
         if (cfg == 0 && pc == 7 && dc.mode == 1 && (!bias || dc.bias_mode == 1)) {
             set_kernel_label("conv1x1_split_pc16_128x128x32%s", in_scale ? "_tf" : "");
             if (in_scale) launch_pw_pc<1, true, 0, false, 4, true>(d, dc, st);
