@@ -506,6 +506,17 @@ extern "C" int scat_conv3x3_s1(const float* src, const float* w, float* dst, int
             cfg = tiles(64, 128) >= thin ? 1 : 2;
             d.RS = (cfg == 2 ? 64 : 128) + 2 * (W + 1);
         }
+        // 32 output channels (HRNet's highest-resolution branch, models/hrnet.py:79-144): a 64-row tile would spend half
+        // of its MFMAs on rows that do not exist — four wavefronts side by side on one 32-row block instead
+        static const int thin32 = [] { const char* e = getenv("SCAT_C3_M32"); return e ? atoi(e) : 1; }();
+        if (Cdst <= 32 && thin32 && !(tuning() >= 1 && tuning() <= 3)) {
+            d.RS = 128 + 2 * (W + 1);
+            set_kernel_label("conv3x3_split_32x128x16%s%s", transposed ? "_dgrad" : "", in_scale ? "_tf" : "");
+            if (in_scale) launch_split<1, 128, true>(d, dc, st);
+            else launch_split<1, 128, false>(d, dc, st);
+            SCAT_LAUNCH_CHECK("scat_conv3x3_s1");
+            return SCAT_OK;
+        }
         set_kernel_label("conv3x3_split_%dx%dx16%s%s", cfg == 0 ? 128 : 64, cfg == 2 ? 64 : 128, transposed ? "_dgrad" : "", in_scale ? "_tf" : "");
         if (in_scale) {
             if (cfg == 0) launch_split<4, 128, true>(d, dc, st);

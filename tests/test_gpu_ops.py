@@ -113,7 +113,8 @@ def test_dgrad_s2_odd_sizes(ops, H, W):
 
 
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 20, 72, 9, 13), (1, 16, 200, 5, 63), (3, 36, 64, 7, 7),
-                                             (2, 64, 132, 30, 4), (5, 128, 128, 14, 14)])
+                                             (2, 64, 132, 30, 4), (5, 128, 128, 14, 14), (3, 32, 32, 20, 24),
+                                             (2, 48, 24, 11, 9)])
 @pytest.mark.parametrize("math", [0, 1])
 def test_conv3x3_halo(ops, math_mode, math, B, cin, cout, H, W):
     """3x3/s1/p1 LDS-halo kernel: ragged channel counts (C % 16 != 0, Cout % 64 != 0), tiles that straddle
