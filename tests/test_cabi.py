@@ -112,3 +112,23 @@ def test_synth_is_deterministic():
     assert abs(float(synth.normal_like(1, "big", (200000,)).std()) - 1.0) < 0.01
     u = synth.uniform(1, "u", (100000,), 2.0, 3.0)
     assert u.min() >= 2.0 and u.max() < 3.0
+
+
+def test_bench_roofline_lookup_matches_profiles():
+    """bench.py prices its roofline kernel's HBM traffic from profiles/r*_traffic.json (rocprofv3 --pmc passes over the
+    bench command): the kernel labels the library reports must map onto the instantiation names that file is keyed by,
+    or `roofline.traffic` silently becomes null."""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    traffic, name = bench.latest_traffic()
+    assert name is not None and traffic, "no profiles/r*_traffic.json"
+    for label in ("conv1x1_split_128x128x32", "conv1x1_split_128x128x32_tf", "conv3x3_split_64x128x16",
+                  "wgrad1x1_split_pc128x128x16_split96", "wgrad3x3_split_pc128x128x16_tf_split86",
+                  "conv7x7_s2_split_64x128x32"):
+        inst = bench.instantiation_of(label)
+        assert inst in traffic, (label, inst, sorted(traffic)[:8])
+        assert traffic[inst]["hbm_bytes_per_launch"] > 0
