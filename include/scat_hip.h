@@ -84,6 +84,12 @@ int scat_vit_qkv_attn_fwd(const float* h, const float* wqkv, float* qkv, float* 
 int64_t scat_conv7x7_s2_fwd_split_ws(int Cout);
 int scat_conv7x7_s2_fwd_split(const float* x, const float* w, float* y, int B, int H, int W, int Cout, void* ws,
                               int64_t ws_bytes, void* stream);
+/* Weight gradient of that stem convolution: dw[64,3,7,7] from dy[B,64,OH,OW] and x[B,3,H,W]; one workgroup walks whole
+ * output rows with the 7 x 3 input rows they touch in LDS, both MFMA operands split in registers, deterministic split
+ * over output rows + fixed-order reduce.  Cout = 64, OW % 16 == 0, OW <= 112.  ws: ..._ws(B, H, W) bytes. */
+int64_t scat_conv7x7_s2_wgrad_split_ws(int B, int H, int W);
+int scat_conv7x7_s2_wgrad_split(const float* dy, const float* x, float* dw, int B, int H, int W, int Cout, void* ws,
+                                int64_t ws_bytes, void* stream);
 /* Pointwise (1x1, stride 1, pad 0) conv: dst[B,M,HW] (+)= A[M,C] . relu(src[B,C,HW]*scale+shift) (+ bias[M]).
  * Weights go straight from L2 to the MFMA operand registers, activations through LDS 32 channels per barrier.
  * transposed = 0 (forward): w = [M,C] = the conv weight [Cout,Cin];  transposed = 1 (data gradient): w = [C,M] is

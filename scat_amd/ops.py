@@ -316,9 +316,15 @@ def conv2d_wgrad(dy, x, w_shape, stride, pad, in_scale=None, in_shift=None, in_r
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w_shape
     dw = out if out is not None else torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    OH, OW = conv_out_hw(H, W, KH, stride, pad)
+    if (KH == 7 and KW == 7 and stride == 2 and pad == 3 and Cin == 3 and Cout == 64 and in_scale is None
+            and OW % 16 == 0 and OW <= 112 and lib().scat_get_math_mode() == 1 and STEM_SPLIT):
+        ws = workspace(lib().scat_conv7x7_s2_wgrad_split_ws(B, H, W), x.device, ws_slot)
+        _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv7x7_s2_wgrad_split, _p(dy), _p(x), _p(dw), B, H, W,
+              Cout, _p(ws), ws.numel(), _stream())
+        return dw
     need = lib().scat_conv2d_wgrad_ws(B, Cin, H, W, Cout, KH, KW, stride, pad)
     ws = workspace(need, x.device, ws_slot)
-    OH, OW = conv_out_hw(H, W, KH, stride, pad)
     _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_wgrad, _p(dy), _p(x), _p(dw), B, Cin, H, W,
           Cout, KH, KW, stride, pad, _p(in_scale), _p(in_shift), int(in_relu), _p(ws), ws.numel(), _stream())
     return dw

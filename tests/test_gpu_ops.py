@@ -150,7 +150,8 @@ def test_conv3x3_halo(ops, math_mode, math, B, cin, cout, H, W):
         ops.HALO = True
 
 
-@pytest.mark.parametrize("B,cout,H,W", [(2, 64, 224, 224), (3, 64, 38, 54), (1, 96, 32, 18), (2, 160, 16, 16)])
+@pytest.mark.parametrize("B,cout,H,W", [(2, 64, 224, 224), (3, 64, 38, 54), (1, 96, 32, 18), (2, 160, 16, 16),
+                                        (3, 64, 30, 64), (5, 64, 22, 32)])
 def test_stem_conv7x7_split(ops, math_mode, B, cout, H, W):
     """models/resnet.py:105: Conv2d(3, 64, 7, stride 2, padding 3) on the split-operand kernel (k-octet = 8 consecutive
     input pixels of one (kh, c)): left / right / top / bottom padding, ragged pixel tiles, more than one row tile,
@@ -169,6 +170,14 @@ def test_stem_conv7x7_split(ops, math_mode, B, cout, H, W):
     finally:
         ops.STEM_SPLIT = True
     assert rel_err(yg, y0.cpu()) < 2e-5
+    # its weight gradient (Cout = 64, output width a multiple of 16): rows in LDS, both operands split in registers
+    if cout == 64 and (W // 2) % 16 == 0:
+        dy = t(92, "dy", tuple(y.shape))
+        xx, ww = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        (dw_ref,) = torch.autograd.grad(F.conv2d(xx, ww, stride=2, padding=3), ww, dy.double())
+        dwg = ops.conv2d_wgrad(g(dy), g(x), tuple(w.shape), 2, 3)
+        assert ops.lib().scat_last_kernel().decode().startswith("wgrad7x7_s2_split")
+        assert rel_err(dwg, dw_ref) < 2e-5
 
 
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 48, 80, 9, 13), (1, 16, 208, 5, 64), (3, 32, 64, 7, 7),
