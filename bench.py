@@ -193,7 +193,7 @@ def cpu_baseline():
                       f"pl_reg, Adam; torch {torch.__version__} CPU, {cores} threads"}
 
 
-def instantiation_of(label):
+def instantiation_of(label, traffic=None):
     """kernel label (scat_last_kernel) -> the template instantiation it launches, as tools/traffic_json.py names it"""
     import re
     tf = "t" if label.endswith("_tf") or "_tf_" in label else "f"
@@ -204,7 +204,13 @@ def instantiation_of(label):
     m = re.search(r"_split_(\d+)x(\d+)x32", label)
     if m:       # pointwise / taps kernel: WM = rows / 32; the stem is the same kernel with the STEM staging
         stem = "t" if label.startswith("conv7x7_s2_split") else "f"
-        return f"conv1x1_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf},{ds},{stem}>"
+        base = f"conv1x1_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf},{ds},{stem}"
+        # one tap and C % 32 == 0 (every pointwise layer of the networks) launch the mask-free staging variant
+        cands = ([f"{base},t>"] if stem == "f" else []) + [f"{base},f>"]
+        for c in cands:
+            if traffic is not None and c in traffic:
+                return c
+        return cands[0]
     m = re.match(r"conv3x3_split_(\d+)x(\d+)x16", label)
     if m:
         return f"conv3x3_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf}>"
@@ -268,7 +274,7 @@ def kernel_rooflines(step, u8, lab):
         # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
         # collected separately, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); null if this kernel was not profiled
         tj, tj_file = latest_traffic()
-        traffic = tj.get(instantiation_of(name), {}).get("hbm_bytes_per_launch")
+        traffic = tj.get(instantiation_of(name, tj), {}).get("hbm_bytes_per_launch")
         # kernels whose label says "split" form each fp32 product from six bf16 MFMA terms: their
         # ceiling for ALGORITHMIC fp32 FLOPs is the dense bf16 MFMA peak / 6; the others use the fp32 MFMA
         split = "_split" in name

@@ -220,9 +220,15 @@ __global__ __launch_bounds__(NT, (BM * BN >= 128 * 128 ? 2 : 3)) void conv1x1_ke
 // pixels (2 oy + kh - 3, 2 ox - 3 .. 2 ox + 4) of channel c, the weight of the eighth is zero; 21 octets padded to 24
 // (d.C = 192): 168 / 147 = 1.14 x the MFMA work of the exact contraction instead of 16 / 3 = 5.3 x for a channel-padded
 // taps layout.  Only the staging addresses differ from the pointwise case.
-template <int WM, int BN, bool TF, bool DS = false, bool STEM = false>
+// PL ("plain": one tap, C % 32 == 0 — every pointwise layer of the networks): no per-load channel bound, and a pixel
+// column past the end of the tensor is left to hold whatever the transform makes of a zero (columns are independent and
+// the epilogue never stores it), so the staging VALU carries no masks at all.  Beside a busy matrix pipe a SIMD issues
+// about one vector instruction per MFMA (tools/mfma_probe.hip, PROBE_PC=1): every instruction taken out of the staging
+// is time given back to the MFMAs.
+template <int WM, int BN, bool TF, bool DS = false, bool STEM = false, bool PL = false>
 __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc dc) {
     static_assert(!(TF && DS), "one input transform at a time");
+    static_assert(!(PL && STEM), "the stem has its own staging");
     static_assert(!STEM || (!TF && !DS), "the stem reads the raw image");
     constexpr int BM = 32 * WM, WN = 4 / WM, NI = BN / (32 * WN);
     constexpr int NIT = 4 * BN / NT;                  // k-octets staged per thread per 32-channel stage
@@ -302,16 +308,17 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 bst[Q][r][m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                    rsrc_b, c + m < d.C ? vbase : OOB, (c0 + 8 * r * (NT / BN) + m) * chw4, 0));
+                    rsrc_b, PL || c + m < d.C ? vbase : OOB, (c0 + 8 * r * (NT / BN) + m) * chw4, 0));
                 if constexpr (DS)
                     bst2[r][m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                        rsrc_b2, c + m < d.C ? vbase : OOB, (c0 + 8 * r * (NT / BN) + m) * chw4, 0));
+                        rsrc_b2, PL || c + m < d.C ? vbase : OOB, (c0 + 8 * r * (NT / BN) + m) * chw4, 0));
             }
         }
     };
     // a staging thread's k-octet is the same for its whole wavefront (BN >= 64): the fused transform's constants are
     // scalar loads
     const int g0u = __builtin_amdgcn_readfirstlane(g0);
+    const float relu_lo = d.relu ? 0.f : -__builtin_inff();     // ReLU as a lower bound: one v_max, no select
     auto store_b = [&](int st, u32x4* dst, auto set_tag) {
         constexpr int Q = decltype(set_tag)::value;
         const int tap = st / nsc, c0 = (st - tap * nsc) * PW_KS;
@@ -328,16 +335,15 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
                     float t = bst[Q][r][m];
                     if constexpr (TF) {
                         const int c = c0 + 8 * (g0u + r * (NT / BN)) + m;
-                        const int cc = c < d.C ? c : 0;
-                        t = fmaf(t, d.scale[cc], d.shift[cc]);
-                        t = d.relu ? fmaxf(t, 0.f) : t;
-                        t = live ? t : 0.f;
+                        const int cc = PL || c < d.C ? c : 0;
+                        t = fmaxf(fmaf(t, d.scale[cc], d.shift[cc]), relu_lo);
+                        if constexpr (!PL) t = live ? t : 0.f;
                     }
                     if constexpr (DS) {
                         const int c = c0 + 8 * (g0u + r * (NT / BN)) + m;
-                        const int cc = c < d.C ? c : 0;
+                        const int cc = PL || c < d.C ? c : 0;
                         t = fmaf(d.coef[cc], t, fmaf(d.coef[d.C + cc], bst2[r][m], d.coef[2 * d.C + cc]));
-                        t = (live && c < d.C) ? t : 0.f;
+                        if constexpr (!PL) t = (live && c < d.C) ? t : 0.f;
                     }
                     x[u] = t;
                 }
@@ -371,10 +377,9 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
                 float t = bst[Q][r][m];
                 if constexpr (TF) {
                     const int c = c0 + 8 * (g0u + r * (NT / BN)) + m;
-                    const int cc = c < d.C ? c : 0;
-                    t = fmaf(t, d.scale[cc], d.shift[cc]);
-                    t = d.relu ? fmaxf(t, 0.f) : t;
-                    t = live ? t : 0.f;
+                    const int cc = PL || c < d.C ? c : 0;
+                    t = fmaxf(fmaf(t, d.scale[cc], d.shift[cc]), relu_lo);
+                    if constexpr (!PL) t = live ? t : 0.f;
                 }
                 x[u] = t;
             }
@@ -1045,11 +1050,23 @@ __global__ void w1x1_t_kernel(const float* __restrict__ w, float* __restrict__ w
     }
 }
 
+static int pw_plain_mode() {
+    static const int m = [] { const char* e = getenv("SCAT_PW_PLAIN"); return e ? atoi(e) : 1; }();
+    return m;
+}
+
 template <int WM, int BN, bool TF, bool DS = false, bool STEM = false>
 static void launch_pw_split(const PwDesc& d, const OutDesc& dc, hipStream_t st) {
     constexpr int BM = 32 * WM;
     const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, BN);
     constexpr size_t lds_bytes = (size_t)2 * 12 * BN * 16;
+    if constexpr (!STEM) {
+        if (d.ntap == 1 && d.C % 32 == 0 && pw_plain_mode()) {
+            hipLaunchKernelGGL((conv1x1_split_kernel<WM, BN, TF, DS, false, true>), dim3(mt * nt), dim3(NT), lds_bytes, st,
+                               d, dc);
+            return;
+        }
+    }
     hipLaunchKernelGGL((conv1x1_split_kernel<WM, BN, TF, DS, STEM>), dim3(mt * nt), dim3(NT), lds_bytes, st, d, dc);
 }
 

@@ -161,37 +161,47 @@ __global__ __launch_bounds__(NT, 3) void wgrad_split_kernel(WgDesc d, OutDesc dc
             bmask[Q] = m;
         }
     };
+    const float relu_lo = d.relu ? 0.f : -__builtin_inff();      // ReLU as a lower bound: one v_max, no select
+    // a whole stage (every staged row has its 8 live pixels — almost all of them) takes the body without the
+    // per-element selects: wave-uniform choice, see wgrad_pc_kernel
     auto store_stage = [&](int buf, auto set_tag) {
         constexpr int Q = decltype(set_tag)::value;
-        if (a_item) {
-            float v[8];
+        auto body_a = [&](auto whole_tag) {
+            constexpr bool WHOLE = decltype(whole_tag)::value;
+            if (a_item) {
+                float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = araw[Q][e];
-                if constexpr (DSA) t = fmaf(aca, t, fmaf(acb, araw2[e], acc_));
-                v[e] = ((amask[Q] >> e) & 1u) ? t : 0.f;
-            }
-            u32x4 hi, mid, lo;
-            split3x8(v, hi, mid, lo);
-            u32x4* p = As(buf) + so * OSA + srow;
-            p[0] = hi; p[2 * OSA] = mid; p[4 * OSA] = lo;
-        }
-        if (b_item) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = braw[Q][e];
-                if constexpr (TF) {
-                    t = fmaf(t, bsc, bsh);
-                    t = d.relu ? fmaxf(t, 0.f) : t;
+                for (int e = 0; e < 8; ++e) {
+                    float t = araw[Q][e];
+                    if constexpr (DSA) t = fmaf(aca, t, fmaf(acb, araw2[e], acc_));
+                    v[e] = WHOLE || ((amask[Q] >> e) & 1u) ? t : 0.f;
                 }
-                v[e] = ((bmask[Q] >> e) & 1u) ? t : 0.f;
+                u32x4 hi, mid, lo;
+                split3x8(v, hi, mid, lo);
+                u32x4* p = As(buf) + so * OSA + srow;
+                p[0] = hi; p[2 * OSA] = mid; p[4 * OSA] = lo;
             }
-            u32x4 hi, mid, lo;
-            split3x8(v, hi, mid, lo);
-            u32x4* p = Bs(buf) + so * OSB + srow;
-            p[0] = hi; p[2 * OSB] = mid; p[4 * OSB] = lo;
-        }
+        };
+        auto body_b = [&](auto whole_tag) {
+            constexpr bool WHOLE = decltype(whole_tag)::value;
+            if (b_item) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = braw[Q][e];
+                    if constexpr (TF) t = fmaxf(fmaf(t, bsc, bsh), relu_lo);
+                    v[e] = WHOLE || ((bmask[Q] >> e) & 1u) ? t : 0.f;
+                }
+                u32x4 hi, mid, lo;
+                split3x8(v, hi, mid, lo);
+                u32x4* p = Bs(buf) + so * OSB + srow;
+                p[0] = hi; p[2 * OSB] = mid; p[4 * OSB] = lo;
+            }
+        };
+        if (__builtin_amdgcn_ballot_w64(a_item && amask[Q] != 0xffu) == 0) body_a(std::true_type{});
+        else body_a(std::false_type{});
+        if (__builtin_amdgcn_ballot_w64(b_item && bmask[Q] != 0xffu) == 0) body_b(std::true_type{});
+        else body_b(std::false_type{});
     };
 
     f32x16 acc[MI][NI];
@@ -349,37 +359,44 @@ __global__ __launch_bounds__(512, 4) void wgrad_pc_kernel(WgDesc d, OutDesc dc) 
                 bmask[Q] = m;
             }
         };
+        const float relu_lo = d.relu ? 0.f : -__builtin_inff();      // ReLU as a lower bound: one v_max, no select
+        // Almost every stage is whole (8 live pixels in every row of the tile): a wave-uniform test picks a body without
+        // the per-element selects — beside a busy matrix pipe the SIMD issues about one vector instruction per MFMA
+        // (tools/mfma_probe.hip, PROBE_PC=1), so the three instructions per element of the masking are worth a branch.
         auto store_stage = [&](u32x4* buf, auto set_tag) {
             constexpr int Q = decltype(set_tag)::value;
-            {
+            auto body_a = [&](auto whole_tag) {
+                constexpr bool WHOLE = decltype(whole_tag)::value;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float t = araw[Q][e];
                     if constexpr (DSA) t = fmaf(aca, t, fmaf(acb, araw2[Q][e], acc_));
-                    v[e] = ((amask[Q] >> e) & 1u) ? t : 0.f;
+                    v[e] = WHOLE || ((amask[Q] >> e) & 1u) ? t : 0.f;
                 }
                 u32x4 hi, mid, lo;
                 split3x8(v, hi, mid, lo);
                 u32x4* p = buf + so * OSA + srow;
                 p[0] = hi; p[2 * OSA] = mid; p[4 * OSA] = lo;
-            }
-            {
+            };
+            auto body_b = [&](auto whole_tag) {
+                constexpr bool WHOLE = decltype(whole_tag)::value;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float t = braw[Q][e];
-                    if constexpr (TF) {
-                        t = fmaf(t, bsc, bsh);
-                        t = d.relu ? fmaxf(t, 0.f) : t;
-                    }
-                    v[e] = ((bmask[Q] >> e) & 1u) ? t : 0.f;
+                    if constexpr (TF) t = fmaxf(fmaf(t, bsc, bsh), relu_lo);
+                    v[e] = WHOLE || ((bmask[Q] >> e) & 1u) ? t : 0.f;
                 }
                 u32x4 hi, mid, lo;
                 split3x8(v, hi, mid, lo);
                 u32x4* p = buf + 6 * OSA + so * OSB + srow;
                 p[0] = hi; p[2 * OSB] = mid; p[4 * OSB] = lo;
-            }
+            };
+            if (__builtin_amdgcn_ballot_w64(amask[Q] != 0xffu) == 0) body_a(std::true_type{});
+            else body_a(std::false_type{});
+            if (__builtin_amdgcn_ballot_w64(bmask[Q] != 0xffu) == 0) body_b(std::true_type{});
+            else body_b(std::false_type{});
         };
         // stage sbeg + k: register set k & 1, LDS buffer k % 3
         load_stage(sbeg, S0{});

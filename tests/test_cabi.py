@@ -129,6 +129,6 @@ def test_bench_roofline_lookup_matches_profiles():
     for label in ("conv1x1_split_128x128x32", "conv1x1_split_128x128x32_tf", "conv3x3_split_64x128x16",
                   "wgrad1x1_split_pc128x128x16_split96", "wgrad3x3_split_pc128x128x16_tf_split86",
                   "conv7x7_s2_split_64x128x32"):
-        inst = bench.instantiation_of(label)
+        inst = bench.instantiation_of(label, traffic)
         assert inst in traffic, (label, inst, sorted(traffic)[:8])
         assert traffic[inst]["hbm_bytes_per_launch"] > 0
