@@ -59,6 +59,11 @@ WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW);
 void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, float* out, int B, int Cin, int H, int W,
                         int Cout, int KK, int stride, const float* in_scale, const float* in_shift, int in_relu,
                         hipStream_t st, const float* dy2 = nullptr, const float* coef3 = nullptr);
+// row-walking 3x3 / stride-1 weight gradient for 32- and 64-channel layers (conv_wgrad_rows.hip)
+bool wgrad_rows_ok(int B, int Cin, int H, int W, int Cout, int KH, int stride, int pad, const void* dy, const void* x);
+int64_t wgrad_rows_ws(int B, int Cin, int H, int W, int Cout);
+int wgrad_rows_launch(const float* dy, const float* x, float* slab, int B, int Cin, int H, int W, int Cout,
+                      const float* in_scale, const float* in_shift, int in_relu, hipStream_t st);
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int splits,
                                      int accumulate);
 // out[e] (+)= sum over slabs, fixed order (vectorised / slab-parallel when n % 4 == 0)

@@ -166,6 +166,10 @@ extern "C" int64_t scat_conv2d_wgrad_ws(int B, int Cin, int H, int W, int Cout, 
         int64_t n2 = q.splits > 1 ? (int64_t)q.splits * q.M * q.N * sizeof(float) : 0;
         if (n2 > need) need = n2;
     }
+    if (wgrad_rows_ok(B, Cin, H, W, Cout, KH, stride, pad, nullptr, nullptr)) {
+        const int64_t n3 = wgrad_rows_ws(B, Cin, H, W, Cout);
+        if (n3 > need) need = n3;
+    }
     return need;
 }
 
@@ -209,6 +213,18 @@ extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int
     SCAT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), SCAT_E_ARG, "scat_conv2d_wgrad: scale/shift pair");
     SCAT_REQUIRE(!(in_scale && KH == 7), SCAT_E_SHAPE, "scat_conv2d_wgrad: fused input transform not built for 7x7");
     if (!in_scale) in_relu = 0;
+    if (math_mode() == 1 && KH == KW && wgrad_rows_ok(B, Cin, H, W, Cout, KH, stride, pad, dy, x) &&
+        fits_i32((int64_t)B * Cout * H * W * 4) && fits_i32((int64_t)B * Cin * H * W * 4)) {
+        const int64_t need3 = wgrad_rows_ws(B, Cin, H, W, Cout);
+        SCAT_REQUIRE(ws && ws_bytes >= need3, SCAT_E_WORKSPACE, "scat_conv2d_wgrad: workspace %lld < %lld bytes",
+                     (long long)ws_bytes, (long long)need3);
+        hipStream_t st3 = (hipStream_t)stream;
+        const int splits = wgrad_rows_launch(dy, x, (float*)ws, B, Cin, H, W, Cout, in_scale, in_shift, in_relu, st3);
+        SCAT_LAUNCH_CHECK("scat_conv2d_wgrad(rows)");
+        launch_splitk_reduce((const float*)ws, dw, (int64_t)Cout * Cin * 9, splits, 0, st3);
+        SCAT_LAUNCH_CHECK("scat_conv2d_wgrad(reduce)");
+        return SCAT_OK;
+    }
     if (math_mode() == 1 && wgrad_split_ok(KH, stride, pad, Cout, Cin)) {
         const WgSplitPlan q = wgrad_split_plan(B, Cin, Cout, KH * KW, OH * OW);
         const int64_t need2 = q.splits > 1 ? (int64_t)q.splits * q.M * q.N * sizeof(float) : 0;

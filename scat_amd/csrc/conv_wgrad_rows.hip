@@ -1,0 +1,299 @@
+// Weight gradient of a 3x3 / stride-1 / pad-1 convolution with FEW channels (Cin, Cout multiples of 32 up to 64:
+// HRNet's 32- and 64-channel branches, models/hrnet.py:38-63, and ResNet layer1's conv2, models/resnet.py:68) on
+// split-operand products:
+//     dW[co][ci][kh][kw] = sum over (n, y, xx)  dy[n][co][y][xx - (kw-1)] * x[n][ci][y + kh - 1][xx]
+// a 32 x 288 output per (Cout block, Cin block) with a contraction over 300 k pixels at batch 96 and 56 x 56.  The
+// general kernel (conv_wgrad_split.hip) gathers x once per tap and splits every element of both operands once per
+// 128-column tile: 9x (x) and 3x (dy) the necessary staging work around 12 MFMAs per wavefront and stage, and beside
+// a busy matrix pipe a SIMD issues about one vector instruction per MFMA (tools/mfma_probe.hip, PROBE_PC=1) — it runs
+// at a tenth of the pipe.  Here a workgroup walks whole image rows:
+//  * each x row (32 channels) is split ONCE into three bf16 planes in LDS and stays there for the three output rows
+//    that read it (ring of four rows); the row above / below an image is simply not multiplied;
+//  * each dy row is split once and written three times, shifted by -1 / 0 / +1 pixels (the kw taps), so every
+//    fragment of every tap is one aligned ds_read_b128: the shift costs four v_alignbit per plane in the producer,
+//    nothing in the consumers;
+//  * consumer wavefront q (0..3) owns the 16-pixel step q of every row and all nine taps: 54 MFMAs on 18 fragment
+//    reads per row, its 32 x 288 partial tile summed with the other three through LDS at the end; four producer
+//    wavefronts load, transform (the fused BatchNorm + ReLU of the layer input), split and write one row ahead.
+// Deterministic split over rows into fp32 slabs [splits][Cout][Cin*9], fixed-order reduce (launch_splitk_reduce).
+#include "conv_common.h"
+#include "split.h"
+
+namespace scat {
+
+struct RowWgDesc {
+    const float* dy;      // [B][Cout][H][W]
+    const float* x;       // [B][Cin][H][W]
+    float* slab;          // [splits][Cout][Cin * 9]
+    const float* scale;   // fused input transform relu(x * scale[ci] + shift[ci]) or nullptr
+    const float* shift;
+    int relu;
+    int B, Cin, Cout, H, W;
+    int rows;             // B * H output rows in total
+    int rpw;              // output rows per workgroup
+    int ncb;              // Cin / 32
+    int noct;             // pixel octets per row held in LDS (2 per 16-pixel step)
+    int nov;              // octets that hold pixels: ceil(W / 8)
+    FastDiv dH;
+    int64_t ndy, nx;
+    int stamp;            // timing experiments only (SCAT_WG_ROWS_STAMP): results are overwritten by time stamps
+};
+
+constexpr int RW_NT = 512;      // wavefronts 0-3: consumers (16-pixel step q = wavefront, all nine taps); 4-7: producers
+
+__global__ __launch_bounds__(RW_NT) void wgrad3x3_rows_kernel(RowWgDesc d) {
+    extern __shared__ __align__(16) float lds[];
+    u32x4* const L = (u32x4*)lds;
+    const int XS = 3 * d.noct * 32;                 // u32x4 per x row slot:  [plane][octet][ci]
+    const int DS = 9 * d.noct * 32;                 // u32x4 per dy buffer:   [shift][plane][octet][co]
+    u32x4* const XR = L;                            // ring of 4 x rows
+    u32x4* const DY = L + 4 * XS;                   // 2 dy buffers
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int cb = blockIdx.x % d.ncb, mb = blockIdx.x / d.ncb, z = blockIdx.z;
+    const int g0 = z * d.rpw, g1 = min(g0 + d.rpw, d.rows);
+    const int N = d.Cin * 9;
+
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if (d.stamp) t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = tid; i < 4 * XS + 2 * DS; i += RW_NT) L[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (g0 >= g1) return;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers: item (row r, octet o)
+        const int pt = tid - 256, r = pt & 31, o = pt >> 5;
+        const bool active = o < d.nov;
+        const __amdgpu_buffer_rsrc_t rsx = make_rsrc(d.x, d.nx), rsy = make_rsrc(d.dy, d.ndy);
+        const int ci = cb * 32 + r, co = mb * 32 + r;
+        float sc = 1.f, sh = 0.f;
+        if (d.scale) { sc = d.scale[ci]; sh = d.shift[ci]; }
+        const float relu_lo = d.relu ? 0.f : -__builtin_inff();
+        const bool tf = d.scale != nullptr;
+        const int nlive = min(8, d.W - 8 * o);                 // pixels of this octet inside the row (W % 4 == 0)
+        auto load_x = [&](int gi, float (&v)[8]) {
+            const bool ok = active && gi >= 0 && gi < d.rows;
+            const uint32_t gg = ok ? (uint32_t)gi : 0u;
+            const uint32_t n = d.dH.div(gg);
+            const int y = (int)(gg - n * (uint32_t)d.H);
+            const int off = ((((int)n * d.Cin + ci) * d.H + y) * d.W + 8 * o) * 4;
+            const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? off : OOB, 0, 0);
+            const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok && nlive > 4 ? off + 16 : OOB, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = __uint_as_float(t0[q]); v[4 + q] = __uint_as_float(t1[q]); }
+        };
+        auto store_x = [&](int gi, const float (&v)[8]) {
+            if (!(active && gi >= 0 && gi < d.rows)) return;
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                t[e] = v[e];
+                if (tf) {
+                    t[e] = fmaxf(fmaf(t[e], sc, sh), relu_lo);
+                    t[e] = e < nlive ? t[e] : 0.f;              // padding stays zero after the transform
+                }
+            }
+            u32x4 hi, mid, lo;
+            split3x8(t, hi, mid, lo);
+            u32x4* p = XR + (gi & 3) * XS + o * 32 + r;
+            p[0] = hi; p[d.noct * 32] = mid; p[2 * d.noct * 32] = lo;
+        };
+        // dy: pixels 8o-1 .. 8o+8 of the row (the two neighbours feed the shifted copies)
+        auto load_dy = [&](int g, float (&v)[10]) {
+            const bool ok = active && g < g1;
+            const uint32_t gg = ok ? (uint32_t)g : 0u;
+            const uint32_t n = d.dH.div(gg);
+            const int y = (int)(gg - n * (uint32_t)d.H);
+            const int off = ((((int)n * d.Cout + co) * d.H + y) * d.W + 8 * o) * 4;
+            const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rsy, ok ? off : OOB, 0, 0);
+            const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rsy, ok && nlive > 4 ? off + 16 : OOB, 0, 0);
+            v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsy, ok && o > 0 ? off - 4 : OOB, 0, 0));
+            v[9] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsy, ok && nlive == 8 && 8 * o + 8 < d.W ? off + 32 : OOB, 0, 0));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[1 + q] = __uint_as_float(t0[q]); v[5 + q] = __uint_as_float(t1[q]); }
+        };
+        auto store_dy = [&](int g, const float (&v)[10]) {
+            if (!(active && g < g1)) return;
+            // pairs (e-1,e0) (e1,e2) (e3,e4) (e5,e6) (e7,e8): dwords 0..3 are the copy for kw = 2 (dy[xx-1]), dwords 1..4 the
+            // copy for kw = 0 (dy[xx+1]); kw = 1 pairs (e0,e1).. = the same halves one bf16 further on
+            uint32_t pa[3][5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) split3(v[2 * j], v[2 * j + 1], pa[0][j], pa[1][j], pa[2][j]);
+            u32x4* base = DY + (g & 1) * DS + o * 32 + r;
+            const int ps = d.noct * 32;                          // plane stride
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                base[(0 * 3 + p) * ps] = u32x4{pa[p][1], pa[p][2], pa[p][3], pa[p][4]};
+                u32x4 mid;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mid[j] = __builtin_amdgcn_alignbit(pa[p][j + 1], pa[p][j], 16);
+                base[(1 * 3 + p) * ps] = mid;
+                base[(2 * 3 + p) * ps] = u32x4{pa[p][0], pa[p][1], pa[p][2], pa[p][3]};
+            }
+        };
+        float xr[8], dr[10];
+        {
+            float xa[8], xb[8], xc[8], da[10];
+            load_x(g0 - 1, xa); load_x(g0, xb); load_x(g0 + 1, xc); load_dy(g0, da);
+            load_x(g0 + 2, xr); load_dy(g0 + 1, dr);
+            store_x(g0 - 1, xa); store_x(g0, xb); store_x(g0 + 1, xc); store_dy(g0, da);
+        }
+        __syncthreads();
+        for (int g = g0; g < g1; ++g) {
+            store_x(g + 2, xr);
+            store_dy(g + 1, dr);
+            load_x(g + 3, xr);
+            load_dy(g + 2, dr);
+            __syncthreads();
+        }
+        __syncthreads();      // the consumers' two reduction rounds
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers: 16-pixel step q = wavefront
+    // (W > 48: four steps per row, one per wavefront; narrower rows leave wavefronts idle), all nine taps each:
+    // 9 dy + 9 x fragment reads and 54 MFMAs per row; the four partial 32 x 288 tiles are summed through LDS at the end
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ks = d.noct >> 1;
+    const int ps = d.noct * 32;
+    f32x16 acc[3][3];                                            // [kh][kw]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][s][i] = 0.f;
+    int y;
+    {
+        const uint32_t n = d.dH.div((uint32_t)g0);
+        y = g0 - (int)n * d.H;
+    }
+    const int frag = lh * 32 + l31;
+    __syncthreads();
+    if (d.stamp) t1 = __builtin_amdgcn_s_memrealtime();
+    for (int g = g0; g < g1; ++g) {
+        for (int q = wave; q < ks; q += 4) {
+            const u32x4* ds = DY + (g & 1) * DS + frag + q * 64;
+            u32x4 a[3][3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[s][p] = ds[(s * 3 + p) * ps];
+            static_for<3>([&](auto kh_tag) {
+                constexpr int KH = decltype(kh_tag)::value;
+                const int yi = y + KH - 1;
+                if (yi >= 0 && yi < d.H) {
+                    const u32x4* xs = XR + ((g + KH + 3) & 3) * XS + frag + q * 64;
+                    u32x4 b[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[p] = xs[p * ps];
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) acc[KH][s] = mfma_split(a[s], b, acc[KH][s]);
+                }
+            });
+        }
+        if (++y == d.H) y = 0;
+        __syncthreads();
+    }
+    if (d.stamp) t2 = __builtin_amdgcn_s_memrealtime();
+    // sum of the four wavefronts' tiles: 2 + 3 -> LDS -> 0 + 1, then 1 -> LDS -> 0 (9 tiles x 16 registers x 64 lanes)
+    float* const R = lds;
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) R[((slot * 9 + a * 3 + s) * 16 + i) * 64 + lane] = acc[a][s][i];
+    };
+    auto add = [&](int slot) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][s][i] += R[((slot * 9 + a * 3 + s) * 16 + i) * 64 + lane];
+    };
+    if (wave >= 2) put(wave - 2);
+    __syncthreads();
+    if (wave < 2) add(wave);
+    __syncthreads();
+    if (wave == 1) put(0);
+    __syncthreads();
+    if (wave == 0) {
+        add(0);
+        // rows = output channels, columns = input channels of this block; column index of dW: ci * 9 + kh * 3 + kw
+        float* out = d.slab + ((int64_t)z * d.Cout + mb * 32) * N + (cb * 32 + l31) * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * lh;
+                    out[(int64_t)row * N + a * 3 + s] = acc[a][s][i];
+                }
+    }
+    __syncthreads();
+    if (d.stamp && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long* o64 = (unsigned long long*)(d.slab + ((int64_t)z * d.Cout + mb * 32) * N + cb * 288);
+        o64[0] = t0; o64[1] = t1; o64[2] = t2; o64[3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+static int wg_rows_mode() {
+    static const int m = [] { const char* e = getenv("SCAT_WG_ROWS"); return e ? atoi(e) : 1; }();
+    return m;
+}
+
+bool wgrad_rows_ok(int B, int Cin, int H, int W, int Cout, int KH, int stride, int pad, const void* dy, const void* x) {
+    return wg_rows_mode() && KH == 3 && stride == 1 && pad == 1 && Cin % 32 == 0 && Cout % 32 == 0 && Cin <= 64 &&
+           Cout <= 64 && W % 4 == 0 && W > 32 && W <= 64 && H >= 2 && (((uintptr_t)dy | (uintptr_t)x) & 15) == 0;
+}
+
+static void rows_plan(int B, int Cin, int H, int W, int Cout, int& rpw, int& splits) {
+    const int rows = B * H, combos = (Cin / 32) * (Cout / 32);
+    const int noct = 2 * ((W + 15) / 16);
+    const int per_cu = noct > 4 ? 1 : 2;                       // workgroups a CU holds (LDS: 15 KB per octet)
+    static const int tgt = [] { const char* e = getenv("SCAT_WG_ROWS_TARGET"); return e ? atoi(e) : 0; }();
+    const int target = tgt > 0 ? tgt : 256 * per_cu;
+    int s = (target + combos - 1) / combos;
+    rpw = (rows + s - 1) / s;
+    if (rpw < 8) rpw = 8;
+    if (rpw > rows) rpw = rows;
+    splits = (rows + rpw - 1) / rpw;
+}
+
+int64_t wgrad_rows_ws(int B, int Cin, int H, int W, int Cout) {
+    int rpw, splits;
+    rows_plan(B, Cin, H, W, Cout, rpw, splits);
+    return (int64_t)splits * Cout * Cin * 9 * sizeof(float);
+}
+
+// slab -> dw by launch_splitk_reduce (caller); returns the number of slabs
+int wgrad_rows_launch(const float* dy, const float* x, float* slab, int B, int Cin, int H, int W, int Cout,
+                      const float* in_scale, const float* in_shift, int in_relu, hipStream_t st) {
+    RowWgDesc d{};
+    d.dy = dy; d.x = x; d.slab = slab; d.scale = in_scale; d.shift = in_shift; d.relu = in_scale ? in_relu : 0;
+    d.B = B; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.rows = B * H; d.ncb = Cin / 32;
+    d.noct = 2 * ((W + 15) / 16); d.nov = (W + 7) / 8;
+    d.dH = FastDiv::make(H);
+    d.ndy = (int64_t)B * Cout * H * W; d.nx = (int64_t)B * Cin * H * W;
+    int splits;
+    rows_plan(B, Cin, H, W, Cout, d.rpw, splits);
+    static const int stamp = [] { const char* e = getenv("SCAT_WG_ROWS_STAMP"); return e ? atoi(e) : 0; }();
+    d.stamp = stamp;
+    const size_t lds_bytes = (size_t)(4 * 3 + 2 * 9) * d.noct * 32 * 16;
+    static bool once = (hipFuncSetAttribute((const void*)wgrad3x3_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)((4 * 3 + 2 * 9) * 8 * 32 * 16)) == hipSuccess);
+    (void)once;
+    set_kernel_label("wgrad3x3_rows_32x288x16%s_split%d", in_scale ? "_tf" : "", splits);
+    hipLaunchKernelGGL(wgrad3x3_rows_kernel, dim3(d.ncb * (Cout / 32), 1, splits), dim3(RW_NT), lds_bytes, st, d);
+    return splits;
+}
+
+}  // namespace scat

@@ -96,6 +96,24 @@ def test_conv_fused_input_transform(ops):
         assert rel_err(dwg, dw_ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W,tf", [(3, 32, 32, 20, 56, False), (2, 64, 64, 9, 44, True), (5, 32, 64, 7, 40, True),
+                                               (2, 64, 32, 5, 52, False), (4, 32, 32, 2, 64, True), (7, 64, 64, 3, 36, False)])
+def test_wgrad3x3_rows(ops, B, cin, cout, H, W, tf):
+    """The row-walking 3x3 weight gradient of the 32/64-channel layers (csrc/conv_wgrad_rows.hip): image borders,
+    partial last octets (W % 8 == 4), three and four 16-pixel steps per row, workgroups whose row range starts / ends
+    inside an image, fused input transform."""
+    x = t(31, "x", (B, cin, H, W))
+    dy = t(32, "dy", (B, cout, H, W))
+    sc = torch.from_numpy(synth.uniform(33, "sc", (cin,), 0.5, 1.5))
+    sh = torch.from_numpy(synth.uniform(34, "sh", (cin,), -0.5, 0.5))
+    a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if tf else x
+    dw_ref = torch.nn.grad.conv2d_weight(a.double(), (cout, cin, 3, 3), dy.double(), stride=1, padding=1)
+    args = (g(sc), g(sh), True) if tf else ()
+    dwg = ops.conv2d_wgrad(g(dy), g(x), (cout, cin, 3, 3), 1, 1, *args)
+    assert ops.lib().scat_last_kernel().decode().startswith("wgrad3x3_rows"), ops.lib().scat_last_kernel()
+    assert rel_err(dwg, dw_ref) < 2e-5
+
+
 @pytest.mark.parametrize("H,W", [(13, 9), (8, 14), (7, 7)])
 def test_dgrad_s2_odd_sizes(ops, H, W):
     """parity classes with ragged class grids (odd heights/widths)"""

@@ -22,6 +22,8 @@ SHAPES = [  # Cin, Cout, k, s, p, H
     (2048, 512, 1, 1, 0, 7), (512, 512, 3, 1, 1, 7),
     # 23-25: the stride-2 shortcut convolutions seen as stride-1 on a pre-subsampled input
     (256, 512, 1, 1, 0, 28), (512, 1024, 1, 1, 0, 14), (1024, 2048, 1, 1, 0, 7),
+    # 26-29: HRNet-W32's branch convolutions (models/hrnet.py:38-63)
+    (32, 32, 3, 1, 1, 56), (64, 64, 3, 1, 1, 28), (128, 128, 3, 1, 1, 14), (256, 256, 3, 1, 1, 7),
 ]
 
 
@@ -45,7 +47,7 @@ def main():
     ap.add_argument("--shapes", default="", help="comma list of shape indices")
     a = ap.parse_args()
     kinds = a.only.split(",") if a.only else ["fwd", "dgrad", "wgrad"]
-    idx = [int(i) for i in a.shapes.split(",")] if a.shapes else range(len(SHAPES))
+    idx = [int(i) for i in a.shapes.split(",")] if a.shapes else range(26)
     B = a.batch
     L = lib()
     print(f"{'shape':34s} {'op':6s} {'kernel':42s} {'us':>8s} {'TF':>7s} {'mfma_us':>8s} {'hbm_us':>7s}")
