@@ -158,6 +158,17 @@ int64_t scat_bn_ws(int B, int C, int HW);
 int scat_bn_train_stats(const float* x, int B, int C, int HW, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
                         float* save_invstd, float* scale, float* shift, void* ws, int64_t ws_bytes, void* stream);
+/* The same statistics without reading the convolution output back (the reference's nn.BatchNorm2d after nn.Conv2d,
+ * models/resnet.py:65-73): scat_epilogue_stats_arm(buf, bytes) before a forward convolution call makes its kernel, if it
+ * is one of the split-operand kernels, leave per-tile row sums (sum, sum of squares; fp32 over <= 128 pixels) in buf
+ * ([C][groups][2] floats; bytes >= C * (ceil(B*OH*OW / 32) + 4) * 8 always suffices); scat_epilogue_stats_groups() right after
+ * the call returns `groups` (0: that kernel does not write them — use scat_bn_train_stats) and disarms.  The state is per
+ * host thread.  scat_bn_train_stats_partials sums the partials in fp64 in a fixed order and finishes as above. */
+int scat_epilogue_stats_arm(float* buf, int64_t bytes);
+int scat_epilogue_stats_groups(void);
+int scat_bn_train_stats_partials(const float* partials, int groups, int B, int C, int HW, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                 float* save_mean, float* save_invstd, float* scale, float* shift, void* stream);
 /* inference: scale/shift from running stats */
 int scat_bn_eval_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, int C, float* scale, float* shift, void* stream);

@@ -10,6 +10,10 @@ namespace scat {
 
 void set_error(const char* fmt, ...);
 void set_kernel_label(const char* fmt, ...);   // which engine instantiation the last call launched
+// scat_epilogue_stats_arm: the next contraction launched from this thread may write per-tile row sums into the armed
+// buffer.  A launcher that supports it calls this with the rows and column groups of its grid: returns the buffer (and
+// records the group count for scat_epilogue_stats_groups) when one is armed and large enough, else nullptr.
+float* epi_stats_take(int rows, int groups);
 
 // Every entry point returns through these: no exception crosses the C boundary.
 #define SCAT_REQUIRE(cond, code, ...)          \

@@ -1056,10 +1056,15 @@ static int pw_plain_mode() {
 }
 
 template <int WM, int BN, bool TF, bool DS = false, bool STEM = false>
-static void launch_pw_split(const PwDesc& d, const OutDesc& dc, hipStream_t st) {
+static void launch_pw_split(const PwDesc& d, const OutDesc& dc_in, hipStream_t st) {
     constexpr int BM = 32 * WM;
     const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, BN);
     constexpr size_t lds_bytes = (size_t)2 * 12 * BN * 16;
+    OutDesc dc = dc_in;
+    if (!dc.accumulate && !dc.bias) {                 // a forward convolution: its BatchNorm's sums ride in the epilogue
+        dc.sg = nt * (4 / WM);
+        dc.stats = epi_stats_take(d.M, dc.sg);
+    }
     if constexpr (!STEM) {
         if (d.ntap == 1 && d.C % 32 == 0 && pw_plain_mode()) {
             hipLaunchKernelGGL((conv1x1_split_kernel<WM, BN, TF, DS, false, true>), dim3(mt * nt), dim3(NT), lds_bytes, st,

@@ -431,10 +431,15 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_split_kernel(HaloDesc d, OutDes
 // (split-operand weights: wt[t][ch][plane][i][16 bf16], the shared re-layout of conv_common.h's WPrepJob with 9 taps)
 
 template <int WM, int HB_N, bool TF>
-static void launch_split(const HaloDesc& d, const OutDesc& dc, hipStream_t st) {
+static void launch_split(const HaloDesc& d, const OutDesc& dc_in, hipStream_t st) {
     constexpr int BM = 32 * WM;
     const int mt = cdiv(d.M, BM), nt = cdiv(d.npix, HB_N);
     const size_t lds_bytes = (size_t)2 * 6 * d.RS * 16;
+    OutDesc dc = dc_in;
+    if (!dc.accumulate && !dc.bias) {                 // a forward convolution: its BatchNorm's sums ride in the epilogue
+        dc.sg = nt * (4 / WM);
+        dc.stats = epi_stats_take(d.M, dc.sg);
+    }
     auto kern = conv3x3_split_kernel<WM, HB_N, TF>;
     hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(NT), lds_bytes, st, d, dc);
 }

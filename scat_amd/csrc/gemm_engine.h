@@ -70,6 +70,9 @@ struct OutDesc {
     int bias_mode;        // 1: bias[i]  2: bias[j]
     int accumulate;       // C += result
     int64_t n;            // floats addressable from p (+ z*sz in mode 0): buffer bounds
+    float* stats;         // optional: per-row (sum, sum of squares) of every wavefront's live columns of the tile,
+    int sg;               //   stats[(row * sg + group) * 2 + {0, 1}], group = tile column * WN + wn  (BatchNorm statistics
+                          //   of a convolution's output without reading it back: scat_epilogue_stats_arm)
 };
 
 // ---------------------------------------------------------------- loaders
@@ -376,6 +379,17 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_impl(F& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_impl<I + 1, N>(f);
+    }
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F f) { static_for_impl<0, N>(f); }
+
 // ---------------------------------------------------------------- epilogue
 // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // Branch-free: 32-bit element offsets, raw buffer stores whose out-of-range lanes (tile edge) are
@@ -457,6 +471,48 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[MI][NI], const OutDesc&
     } else {
         if (biasi) emit(std::false_type{}, std::true_type{});
         else emit(std::false_type{}, std::false_type{});
+    }
+    if (dc.stats) {
+        // Row sums of the tile while it is still in registers.  A row's columns sit in NI registers x 32 lanes: add the
+        // NI registers, then a reduce-scatter over the 32 lanes (step with lane bit k: a lane keeps the half of its
+        // registers whose index bit matches and adds the partner's) — 16 + 8 + 4 + 2 + 1 exchanges per quantity instead
+        // of 16 x 5; lane l ends with the total of accumulator register (l >> 1) & 15.
+        const int grp = (j0 / BN) * WN + wn;
+#pragma unroll
+        for (int a = 0; a < MI; ++a) {
+            float s[16], q[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int b = 0; b < NI; ++b) {
+                    const float v = colok[b] ? acc[a][b][r] : 0.f;
+                    ss += v;
+                    qq = fmaf(v, v, qq);
+                }
+                s[r] = ss; q[r] = qq;
+            }
+            static_for<4>([&](auto st_tag) {
+                constexpr int ST = decltype(st_tag)::value, H = 8 >> ST, BIT = 16 >> ST;
+                const bool up = (lane & BIT) != 0;
+#pragma unroll
+                for (int k = 0; k < H; ++k) {
+                    const float ks = up ? s[k + H] : s[k], xs = up ? s[k] : s[k + H];
+                    const float kq = up ? q[k + H] : q[k], xq = up ? q[k] : q[k + H];
+                    s[k] = ks + __shfl_xor(xs, BIT);
+                    q[k] = kq + __shfl_xor(xq, BIT);
+                }
+            });
+            s[0] += __shfl_xor(s[0], 1);
+            q[0] += __shfl_xor(q[0], 1);
+            const int r = (lane >> 1) & 15;
+            const int i = ibase + a * 32 + (r & 3) + 8 * (r >> 2);
+            if ((lane & 1) == 0 && i < M) {
+                float* o = dc.stats + ((int64_t)i * dc.sg + grp) * 2;
+                o[0] = s[0];
+                o[1] = q[0];
+            }
+        }
     }
 }
 

@@ -27,6 +27,16 @@ void set_kernel_label(const char* fmt, ...) {
     va_end(ap);
 }
 
+struct EpiStats { float* buf; int64_t cap; int groups; };
+static thread_local EpiStats g_epi = {nullptr, 0, 0};
+float* epi_stats_take(int rows, int groups) {
+    float* b = g_epi.buf;
+    g_epi.buf = nullptr;
+    if (!b || (int64_t)rows * groups * 2 > g_epi.cap) return nullptr;
+    g_epi.groups = groups;
+    return b;
+}
+
 static int g_math_mode = -1;
 int math_mode() {
     if (g_math_mode < 0) {
@@ -618,4 +628,17 @@ extern "C" int scat_adam(float* p, const float* g, float* m, float* v, int64_t n
                        beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
     SCAT_LAUNCH_CHECK("scat_adam");
     return SCAT_OK;
+}
+
+extern "C" int scat_epilogue_stats_arm(float* buf, int64_t bytes) {
+    scat::g_epi.buf = buf;
+    scat::g_epi.cap = buf ? bytes / 4 : 0;
+    scat::g_epi.groups = 0;
+    return SCAT_OK;
+}
+extern "C" int scat_epilogue_stats_groups(void) {
+    const int g = scat::g_epi.groups;
+    scat::g_epi.buf = nullptr;
+    scat::g_epi.groups = 0;
+    return g;
 }

@@ -149,6 +149,29 @@ __global__ __launch_bounds__(1024) void bn_stats_fin_kernel(const float* __restr
     }
 }
 
+// Statistics from the row sums a convolution's epilogue left behind (OutDesc::stats, gemm_engine.h store_tile):
+// part[c][G][2] = (sum, sum of squares) of channel c over column group g, fp32; summed here in fp64, fixed order.
+__global__ __launch_bounds__(256) void bn_partials_fin_kernel(const float* __restrict__ part, int G, double count,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ rmean,
+                                                               float* __restrict__ rvar, float momentum, float eps,
+                                                               float* __restrict__ save_mean,
+                                                               float* __restrict__ save_invstd, float* __restrict__ scale,
+                                                               float* __restrict__ shift) {
+    const int c = blockIdx.x;
+    const float2* p = (const float2*)part + (int64_t)c * G;
+    double s1 = 0, s2 = 0;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        const float2 v = p[g];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+    __shared__ double sh[8];
+    block_sum2(s1, s2, sh);
+    if (threadIdx.x == 0)
+        bn_finish(c, s1, s2, count, gamma, beta, rmean, rvar, momentum, eps, save_mean, save_invstd, scale, shift);
+}
+
 __global__ void bn_eval_fold_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
                                     float eps, int C, float* scale, float* shift) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -561,6 +584,22 @@ extern "C" int scat_bn_train_stats(const float* x, int B, int C, int HW, const f
                        (double)B * HW, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
                        scale, shift);
     SCAT_LAUNCH_CHECK("scat_bn_train_stats");
+    return SCAT_OK;
+}
+
+extern "C" int scat_bn_train_stats_partials(const float* partials, int groups, int B, int C, int HW, const float* gamma,
+                                            const float* beta, float* running_mean, float* running_var, float momentum,
+                                            float eps, float* save_mean, float* save_invstd, float* scale, float* shift,
+                                            void* stream) {
+    SCAT_REQUIRE(partials && gamma && beta && save_mean && save_invstd && scale && shift, SCAT_E_ARG,
+                 "scat_bn_train_stats_partials: null pointer");
+    SCAT_REQUIRE(B > 0 && C > 0 && HW > 0 && groups > 0, SCAT_E_SHAPE, "scat_bn_train_stats_partials: non-positive dimension");
+    SCAT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), SCAT_E_ARG,
+                 "scat_bn_train_stats_partials: running pair");
+    hipLaunchKernelGGL(bn_partials_fin_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, groups,
+                       (double)B * HW, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale,
+                       shift);
+    SCAT_LAUNCH_CHECK("scat_bn_train_stats_partials");
     return SCAT_OK;
 }
 

@@ -39,16 +39,7 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& hi, u32x4& 
         hi[q] = h; mid[q] = m; lo[q] = l;
     }
 }
-// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for_impl(F& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for_impl<I + 1, N>(f);
-    }
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F f) { static_for_impl<0, N>(f); }
+// (static_for<N>: gemm_engine.h)
 
 // acc += a * b with the six significant terms, small ones first
 __device__ __forceinline__ f32x16 mfma_split(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 c) {

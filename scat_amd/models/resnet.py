@@ -104,20 +104,20 @@ def _block_forward(blk, xin, training, wp=None):
     """Bottleneck.forward (models/resnet.py:78-98) as a kernel sequence -> tape record
     (blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out, omask).  bn1/bn2's normalise+ReLU live in the operand load of
     the next convolution; bn3 (+ the shortcut's BatchNorm) + residual + ReLU is the one pass that writes the output."""
-    c1 = ops.conv2d_fwd(xin, blk.conv1.weight, 1, 0, wp=wp)
+    c1 = ops.conv2d_fwd(xin, blk.conv1.weight, 1, 0, wp=wp, stats=training)
     s1 = _BNState(c1, blk.bn1, training)
-    c2 = ops.conv2d_fwd(c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True, wp=wp)
+    c2 = ops.conv2d_fwd(c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True, wp=wp, stats=training)
     s2 = _BNState(c2, blk.bn2, training)
-    c3 = ops.conv2d_fwd(c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True, wp=wp)
+    c3 = ops.conv2d_fwd(c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True, wp=wp, stats=training)
     s3 = _BNState(c3, blk.bn3, training)
     if blk.downsample is not None:
         # stride-2 shortcut: pack the pixels it reads once, then it (and its weight gradient) is a
         # stride-1 pointwise convolution
         xs = ops.subsample2(xin) if blk.stride == 2 and SUBSAMPLE else None
         if xs is not None:
-            cd = ops.conv2d_fwd(xs, blk.downsample[0].weight, 1, 0, wp=wp)
+            cd = ops.conv2d_fwd(xs, blk.downsample[0].weight, 1, 0, wp=wp, stats=training)
         else:
-            cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0, wp=wp)
+            cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0, wp=wp, stats=training)
         sd = _BNState(cd, blk.downsample[1], training)
         sd.xs = xs if training else None
         res, rsc, rsh = cd, sd.scale, sd.shift      # the shortcut's BatchNorm is applied while adding
@@ -316,7 +316,7 @@ class _BackboneFn(torch.autograd.Function):
         if part != 2:
             wp.run(training)       # one launch re-lays every convolution weight for this step (ops.WeightPrep)
             # stem: conv7x7/2 -> [BN -> ReLU -> maxpool fused]
-            c0 = ops.conv2d_fwd(x, net.conv1.weight, 2, 3)
+            c0 = ops.conv2d_fwd(x, net.conv1.weight, 2, 3, stats=training)
             s0 = _BNState(c0, net.bn1, training)
             cur, idx0 = ops.maxpool_fwd(c0, s0.scale, s0.shift, True)
         else:

@@ -221,8 +221,37 @@ def _pw_ok(KH, KW, stride, pad, csrc, *ts):
             and all(t is None or t.data_ptr() % 16 == 0 for t in ts))
 
 
-def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, bias=None, out=None, wp=None):
-    """wp: the network's WeightPrep (prepared weights), or None: the call re-lays its weights itself"""
+EPI_STATS = os.environ.get("SCAT_EPI_STATS", "1") != "0"   # BatchNorm sums in the convolution epilogue (0: separate pass)
+
+
+def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, bias=None, out=None, wp=None,
+               stats=False):
+    """wp: the network's WeightPrep (prepared weights), or None: the call re-lays its weights itself.
+    stats: a training-mode BatchNorm follows — ask the kernel to leave the per-tile channel sums of its output behind
+    (include/scat_hip.h scat_epilogue_stats_arm); ``y.scat_stats`` = (partials, groups) when it did, for
+    ``bn_train_stats`` to finish without reading y back."""
+    if not (stats and EPI_STATS and bias is None):
+        return _conv2d_fwd(x, w, stride, pad, in_scale, in_shift, in_relu, bias, out, wp)
+    B, _, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    OH, OW = conv_out_hw(H, W, KH, stride, pad)
+    nbytes = Cout * ((B * OH * OW + 31) // 32 + 4) * 8      # a column group is >= 32 pixels; + the ragged last tile
+    part = workspace(nbytes, x.device, "bnpart")
+    lib().scat_epilogue_stats_arm(_p(part), nbytes)
+    try:
+        y = _conv2d_fwd(x, w, stride, pad, in_scale, in_shift, in_relu, bias, out, wp)
+    finally:
+        groups = lib().scat_epilogue_stats_groups()
+    # the partials live in a recycled workspace: they are only good until the next armed convolution on this stream
+    _EPI_GEN[0] += 1
+    y.scat_stats = (part, groups, _EPI_GEN[0]) if groups > 0 else None
+    return y
+
+
+_EPI_GEN = [0]
+
+
+def _conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, bias=None, out=None, wp=None):
     _chk(x, w, in_scale, in_shift, bias)
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
@@ -406,10 +435,21 @@ def colsum(x2d, out=None, accumulate=False):
 # ---------------------------------------------------------------- BatchNorm
 
 def bn_train_stats(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
-    """-> (save_mean, save_invstd, scale, shift); running stats updated in place."""
+    """-> (save_mean, save_invstd, scale, shift); running stats updated in place.  When x came out of
+    ``conv2d_fwd(..., stats=True)`` with its channel sums, they are finished from those (no pass over x)."""
     _chk(x, gamma, beta, running_mean, running_var)
     B, C, H, W = x.shape
     o = torch.empty((4, C), dtype=torch.float32, device=x.device)
+    st = getattr(x, "scat_stats", None)
+    if st is not None and st[2] != _EPI_GEN[0]:
+        st = x.scat_stats = None       # another convolution has used the workspace since: take the pass over x
+    if st is not None:
+        part, groups, _ = st
+        x.scat_stats = None            # one use: the workspace behind it is recycled by the next convolution
+        _prof_hbm("bn_train_stats_partials", 8.0 * C * groups, lib().scat_bn_train_stats_partials, _p(part), groups, B, C,
+                  H * W, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps, _p(o[0]), _p(o[1]),
+                  _p(o[2]), _p(o[3]), _stream())
+        return o[0], o[1], o[2], o[3]
     ws = workspace(lib().scat_bn_ws(B, C, H * W), x.device)
     # algorithmic traffic: one read of x
     _prof_hbm("bn_train_stats", 4.0 * x.numel(), lib().scat_bn_train_stats, _p(x), B, C, H * W, _p(gamma), _p(beta),

@@ -457,6 +457,36 @@ def test_batchnorm(ops, B, C, H):
     assert rel_err(ops.bn_apply(xg, sc_e, sh_e), ye) < 1e-5
 
 
+@pytest.mark.parametrize("B,cin,cout,k,s,p,H,W", [(3, 64, 256, 1, 1, 0, 28, 28), (2, 128, 64, 1, 1, 0, 13, 9),
+                                                   (3, 64, 64, 3, 1, 1, 20, 24), (2, 32, 32, 3, 1, 1, 11, 9),
+                                                   (2, 128, 128, 3, 2, 1, 28, 28), (2, 3, 64, 7, 2, 3, 64, 96),
+                                                   (5, 256, 96, 1, 1, 0, 7, 7), (2, 64, 128, 1, 2, 0, 14, 14)])
+def test_conv_epilogue_batchnorm_statistics(ops, B, cin, cout, k, s, p, H, W):
+    """conv2d_fwd(stats=True): the kernel leaves per-tile channel sums of its output behind and bn_train_stats finishes
+    from them — same mean / invstd / scale / shift / running statistics as the pass over the output (and as torch),
+    ragged last tiles and dead columns included."""
+    x = t(61, "x", (B, cin, H, W)) * 1.3 + 0.2
+    w = t(62, "w", (cout, cin, k, k), std=(2.0 / (cin * k * k)) ** 0.5)
+    gamma = torch.from_numpy(synth.uniform(63, "g", (cout,), 0.5, 1.5))
+    beta = torch.from_numpy(synth.uniform(64, "b", (cout,), -0.3, 0.3))
+    y_ref = F.conv2d(x.double(), w.double(), stride=s, padding=p)
+    rm_ref, rv_ref = torch.zeros(cout, dtype=torch.float64), torch.ones(cout, dtype=torch.float64)
+    F.batch_norm(y_ref, rm_ref, rv_ref, gamma.double(), beta.double(), True, 0.1, 1e-5)
+    mean_ref = y_ref.mean(dim=(0, 2, 3))
+    invstd_ref = 1.0 / torch.sqrt(y_ref.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    y = ops.conv2d_fwd(g(x), g(w), s, p, stats=True)
+    assert getattr(y, "scat_stats", None) is not None, ops.lib().scat_last_kernel()
+    assert rel_err(y, y_ref) < 2e-5
+    rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    mean, invstd, scale, shift = ops.bn_train_stats(y, g(gamma), g(beta), rm, rv)
+    assert y.scat_stats is None                      # consumed
+    rm2, rv2 = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    mean2, invstd2, scale2, shift2 = ops.bn_train_stats(y, g(gamma), g(beta), rm2, rv2)      # the pass over y
+    for a, b, ref in ((mean, mean2, mean_ref), (invstd, invstd2, invstd_ref), (rm, rm2, rm_ref), (rv, rv2, rv_ref)):
+        assert rel_err(a, ref) < 2e-5 and rel_err(a, b.cpu()) < 2e-6
+    assert rel_err(scale, scale2.cpu()) < 2e-6 and rel_err(shift, shift2.cpu()) < 2e-5
+
+
 def test_batchnorm_sign_mask(ops):
     """bn_bwd from the 1-bit sign mask of the block output == bn_bwd from the output itself, bit for bit."""
     B, C, H = 3, 64, 28

@@ -15,6 +15,8 @@ def test_switches_do_not_change_the_numbers():
     from tools import ab_check
 
     a, b = ab_check.run(13, {}), ab_check.run(13, ab_check.OFF)
-    assert a[0] == b[0], (a, b)
+    # (the first loss used to be bit-identical; with the BatchNorm sums taken in the convolution epilogues — fp32 over
+    # each tile's columns, then fp64 — it depends on the tile shape of the kernel that ran, at the 1e-7 level)
+    assert abs(a[0] - b[0]) / abs(b[0]) < 2e-6, (a, b)
     for u, v in zip(a[1:], b[1:]):
         assert abs(u - v) / abs(v) < 5e-2, (a, b)

@@ -1,12 +1,12 @@
 """Numerical A/B of the scheduling switches: a few train steps at an odd batch size with every overlap / fold / cache
 enabled versus all of them disabled (single stream, per-call weight re-layout, unfolded BatchNorm backward, late
-Adam).  The two runs must give the same losses up to fp32 summation-order effects."""
+Adam, BatchNorm statistics from a pass over the convolution output instead of its epilogue).  The two runs must give the same losses up to fp32 summation-order effects."""
 import os
 import subprocess
 import sys
 
 OFF = dict(SCAT_OVERLAP_TOKENS="0", SCAT_SIDE_WGRAD="0", SCAT_EARLY_ADAM="0", SCAT_WPREP="0", SCAT_BNB="0",
-           SCAT_SUBSAMPLE="0", SCAT_DX2_FOLD="0", SCAT_SIDE_HEAD="0")
+           SCAT_SUBSAMPLE="0", SCAT_DX2_FOLD="0", SCAT_SIDE_HEAD="0", SCAT_EPI_STATS="0")
 CHILD = r'''
 import sys, random, torch
 sys.path.insert(0, ".")
