@@ -214,6 +214,10 @@ def instantiation_of(label, traffic=None):
     m = re.match(r"conv3x3_split_(\d+)x(\d+)x16", label)
     if m:
         return f"conv3x3_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf}>"
+    if label.startswith("wgrad3x3_rows"):
+        return "wgrad3x3_rows_kernel"
+    if label.startswith("wgrad7x7_s2_split"):
+        return "stem_wgrad_split_kernel"
     m = re.match(r"wgrad(1x1|3x3)(_s2)?_split_pc128x128x16", label)
     if m:
         return f"wgrad_pc_kernel<{9 if m.group(1) == '3x3' else 1},{tf},{'t' if m.group(2) else 'f'},{ds}>"

@@ -40,8 +40,15 @@ tools/pmc_run.sh $O/pmc_wait "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACT
 echo "[profiles] probes"
 # 5. calibration probe, per-shape table, ViT tables
 timeout -k 10 120 tools/_bin/mfma_probe > $O/r02_mfma_probe.txt 2>&1
+PROBE_PC=1 timeout -k 10 120 tools/_bin/mfma_probe > $O/r02_mfma_probe_pc.txt 2>&1
 echo "[profiles] conv shapes"
 timeout -k 10 300 python tools/conv_bench.py --reps 10 > $O/r02_conv_shapes.txt 2>&1
+timeout -k 10 300 python tools/conv_bench.py --reps 10 --shapes 26,27,28,29 > $O/r02_conv_shapes_hrnet.txt 2>&1
+echo "[profiles] hrnet kernel summary"
+rm -rf $O/prof_hrnet
+( cd /tmp && SCAT_SIDE_WGRAD=0 SCAT_OVERLAP_TOKENS=0 SCAT_EARLY_ADAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_hrnet -o run -- python3 $GRAFT_REPO_ROOT/bench.py --config hrnet_w32 --steps 6 --warmup 3 --no-cpu-baseline --no-roofline > $O/prof_hrnet.log 2>&1 )
+python3 tools/prof_summary.py $(find $O/prof_hrnet -name 'run_kernel_stats.csv' | head -1) 9 70 > $O/r02_hrnet_kernel_summary_serialized.txt 2>&1
+rm -rf $O/prof_hrnet
 echo "[profiles] vit"
 timeout -k 10 200 python tools/vit_fused_bench.py > $O/r02_vit_fused.txt 2>&1
 timeout -k 10 300 python tools/vit_gemm_bench.py > $O/r02_vit_gemm.txt 2>&1
