@@ -46,7 +46,15 @@ def _prof_hbm(name, nbytes, fn, *args):
     return r
 
 
+# torch.cuda.current_stream() builds a Stream object and walks the device-index helpers (8-10 us a call, 1 300 calls in
+# an HRNet-W32 step: that configuration is bound by the host); the raw handle is what the C ABI wants anyway
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -63,10 +71,13 @@ def _chk(*ts):
                             f"contiguous={t.is_contiguous()} (no CPU fallback on the product path)")
 
 
+_HAVE_GPU = torch.cuda.is_available()
+
+
 def workspace(nbytes: int, device, slot: str = "default") -> torch.Tensor:
     """Caller-owned scratch, grown on demand, one buffer per (device, slot, current stream): reuse is stream-ordered,
     and work issued on another stream (weight gradients, the downsample branch) gets its own buffer."""
-    key = (str(device), slot, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
+    key = (device if isinstance(device, str) else (device.type, device.index), slot, _stream() if _HAVE_GPU else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

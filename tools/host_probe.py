@@ -16,13 +16,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=96)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--config", default="resnet50", choices=["resnet50", "hrnet_w32", "performer"])
     ap.add_argument("--sync-debug", action="store_true")
     ap.add_argument("--hi", action="store_true", help="run the step on a high-priority stream (side streams stay normal)")
     a = ap.parse_args()
     from scat_amd.trainer import TrainStep
 
     dev = torch.device("cuda", 0)
-    net = bench.make_net("resnet50", 1, dev)
+    net = bench.make_net(a.config, 1, dev)
     ts = TrainStep(net, lr=5e-4)
     u8, lab = bench.build_inputs(a.batch, 100, dev)
     from scat_amd import ops as _ops
