@@ -245,25 +245,250 @@ __global__ __launch_bounds__(RW_NT) void wgrad3x3_rows_kernel(RowWgDesc d) {
     }
 }
 
+// ---------------------------------------------------------------- 64 x 64 blocks, rows of at most 32 pixels
+//
+// The same walk for the narrower feature maps (W <= 32: 28 x 28, 14 x 14, 7 x 7) of layers with 64 .. 512 channels: a
+// workgroup owns a 64 (Cout) x 64 (Cin) block of dW — four 32 x 32 sub-blocks, one per consumer wavefront (mi, ci), nine
+// taps each, no reduction between wavefronts — and RPI image rows per barrier interval (two for W <= 16, where a row is a
+// single 16-pixel step).  x rows live in a ring of 4 RPI slots, dy rows (three shifted copies) in 2 RPI buffers; producer
+// lane (r, o, j): channel r of the block, pixel octet o, row j of the group.  Every element of x is split Cout / 64
+// times and every element of dy Cin / 64 times in total, instead of 9 Cout / 128 and Cin 9 / 128.
+struct RowWg64Desc {
+    const float* dy;
+    const float* x;
+    float* slab;
+    const float* scale;
+    const float* shift;
+    int relu;
+    int B, Cin, Cout, H, W;
+    int rows, rpw, ncb, noct, nov, rpi;
+    FastDiv dH;
+    int64_t ndy, nx;
+};
+
+template <int RPI>
+__global__ __launch_bounds__(512) void wgrad3x3_rows64_kernel(RowWg64Desc d) {
+    constexpr int NX = 4 * RPI, ND = 2 * RPI, NG = RPI == 1 ? 3 : 2;     // ring sizes (rows); x row groups a consumer needs
+    extern __shared__ __align__(16) float lds[];
+    u32x4* const L = (u32x4*)lds;
+    const int XS = 3 * d.noct * 64;                 // u32x4 per x row slot:  [plane][octet][ci 64]
+    const int DS = 9 * d.noct * 64;                 // u32x4 per dy row:      [shift][plane][octet][co 64]
+    u32x4* const XR = L;
+    u32x4* const DY = L + NX * XS;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int cb = blockIdx.x % d.ncb, mb = blockIdx.x / d.ncb, z = blockIdx.z;
+    const int g0 = z * d.rpw, g1 = min(g0 + d.rpw, d.rows);
+    const int N = d.Cin * 9;
+    const int nit = (g1 - g0 + RPI - 1) / RPI;
+
+    for (int i = tid; i < NX * XS + ND * DS; i += 512) L[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (g0 >= g1) return;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pt = tid - 256, r = pt & 63;
+        const int o = (pt >> 6) % d.nov, j = (pt >> 6) / d.nov;           // octet, row of the group
+        const bool active = j < RPI;
+        const __amdgpu_buffer_rsrc_t rsx = make_rsrc(d.x, d.nx), rsy = make_rsrc(d.dy, d.ndy);
+        const int ci = cb * 64 + r, co = mb * 64 + r;
+        float sc = 1.f, sh = 0.f;
+        if (d.scale) { sc = d.scale[ci]; sh = d.shift[ci]; }
+        const float relu_lo = d.relu ? 0.f : -__builtin_inff();
+        const bool tf = d.scale != nullptr;
+        const int nlive = min(8, d.W - 8 * o);
+        const bool al4 = (d.W & 3) == 0;
+        const int ps = d.noct * 64;
+        // x row group k = rows g0 - 1 + k RPI + j; dy row group k = rows g0 + k RPI + j
+        auto load_x = [&](int k, float (&v)[8]) {
+            const int gi = g0 - 1 + k * RPI + j;
+            const bool ok = active && gi >= 0 && gi < d.rows;
+            const uint32_t gg = ok ? (uint32_t)gi : 0u;
+            const uint32_t n = d.dH.div(gg);
+            const int y = (int)(gg - n * (uint32_t)d.H);
+            const int off = ((((int)n * d.Cin + ci) * d.H + y) * d.W + 8 * o) * 4;
+            if (al4) {
+                const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? off : OOB, 0, 0);
+                const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok && nlive > 4 ? off + 16 : OOB, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] = __uint_as_float(t0[q]); v[4 + q] = __uint_as_float(t1[q]); }
+            } else {                                            // rows that are not 16-byte multiples (14, 7 pixels)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsx, ok && e < nlive ? off + 4 * e : OOB, 0, 0));
+            }
+        };
+        auto store_x = [&](int k, const float (&v)[8]) {
+            const int gi = g0 - 1 + k * RPI + j;
+            if (!(active && gi >= 0 && gi < d.rows)) return;
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                t[e] = v[e];
+                if (tf) {
+                    t[e] = fmaxf(fmaf(t[e], sc, sh), relu_lo);
+                    t[e] = e < nlive ? t[e] : 0.f;
+                }
+            }
+            u32x4 hi, mid, lo;
+            split3x8(t, hi, mid, lo);
+            u32x4* p = XR + (gi & (NX - 1)) * XS + o * 64 + r;
+            p[0] = hi; p[ps] = mid; p[2 * ps] = lo;
+        };
+        auto load_dy = [&](int k, float (&v)[10]) {
+            const int g = g0 + k * RPI + j;
+            const bool ok = active && g < g1;
+            const uint32_t gg = ok ? (uint32_t)g : 0u;
+            const uint32_t n = d.dH.div(gg);
+            const int y = (int)(gg - n * (uint32_t)d.H);
+            const int off = ((((int)n * d.Cout + co) * d.H + y) * d.W + 8 * o) * 4;
+            v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsy, ok && o > 0 ? off - 4 : OOB, 0, 0));
+            v[9] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsy, ok && nlive == 8 && 8 * o + 8 < d.W ? off + 32 : OOB, 0, 0));
+            if (al4) {
+                const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rsy, ok ? off : OOB, 0, 0);
+                const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rsy, ok && nlive > 4 ? off + 16 : OOB, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[1 + q] = __uint_as_float(t0[q]); v[5 + q] = __uint_as_float(t1[q]); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    v[1 + e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsy, ok && e < nlive ? off + 4 * e : OOB, 0, 0));
+            }
+        };
+        auto store_dy = [&](int k, const float (&v)[10]) {
+            const int g = g0 + k * RPI + j;
+            if (!(active && g < g1)) return;
+            uint32_t pa[3][5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) split3(v[2 * q], v[2 * q + 1], pa[0][q], pa[1][q], pa[2][q]);
+            u32x4* base = DY + (g & (ND - 1)) * DS + o * 64 + r;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                base[(0 * 3 + p) * ps] = u32x4{pa[p][1], pa[p][2], pa[p][3], pa[p][4]};
+                u32x4 mid;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mid[q] = __builtin_amdgcn_alignbit(pa[p][q + 1], pa[p][q], 16);
+                base[(1 * 3 + p) * ps] = mid;
+                base[(2 * 3 + p) * ps] = u32x4{pa[p][0], pa[p][1], pa[p][2], pa[p][3]};
+            }
+        };
+        float xr[8], dr[10];
+        {
+            float xa[NG][8], da[10];
+#pragma unroll
+            for (int k = 0; k < NG; ++k) load_x(k, xa[k]);
+            load_dy(0, da);
+            load_x(NG, xr);
+            load_dy(1, dr);
+#pragma unroll
+            for (int k = 0; k < NG; ++k) store_x(k, xa[k]);
+            store_dy(0, da);
+        }
+        __syncthreads();
+        for (int it = 0; it < nit; ++it) {
+            store_x(it + NG, xr);
+            store_dy(it + 1, dr);
+            load_x(it + NG + 1, xr);
+            load_dy(it + 2, dr);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers: sub-block (mi, ci), nine taps
+    const int mi = wave >> 1, cw = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ks = d.noct >> 1;
+    const int ps = d.noct * 64;
+    f32x16 acc[3][3];                                            // [kh][kw]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][s][i] = 0.f;
+    int y;
+    {
+        const uint32_t n = d.dH.div((uint32_t)g0);
+        y = g0 - (int)n * d.H;
+    }
+    const int fa = lh * 64 + mi * 32 + l31, fb = lh * 64 + cw * 32 + l31;
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+        // the RPI rows of the group are RPI * ks steps of one loop: step u = (row jr, 16-pixel step q)
+        for (int u = 0; u < RPI * ks; ++u) {
+            const int jr = RPI == 1 ? 0 : u / ks, q = RPI == 1 ? u : u - jr * ks;
+            const int g = g0 + it * RPI + jr;
+            int yr = y + jr;
+            if (yr >= d.H) yr -= d.H;
+            if (g < g1) {
+                const u32x4* ds = DY + (g & (ND - 1)) * DS + fa + q * 128;
+                u32x4 a[3][3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[s][p] = ds[(s * 3 + p) * ps];
+                static_for<3>([&](auto kh_tag) {
+                    constexpr int KH = decltype(kh_tag)::value;
+                    const int yi = yr + KH - 1;
+                    if (yi >= 0 && yi < d.H) {
+                        const u32x4* xs = XR + ((g + KH - 1 + NX) & (NX - 1)) * XS + fb + q * 128;
+                        u32x4 b[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) b[p] = xs[p * ps];
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) acc[KH][s] = mfma_split(a[s], b, acc[KH][s]);
+                    }
+                });
+            }
+        }
+        y += RPI;
+        if (y >= d.H) y -= d.H;
+        __syncthreads();
+    }
+    float* out = d.slab + ((int64_t)z * d.Cout + mb * 64 + mi * 32) * N + (cb * 64 + cw * 32 + l31) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * lh;
+                out[(int64_t)row * N + a * 3 + s] = acc[a][s][i];
+            }
+}
+
 static int wg_rows_mode() {
     static const int m = [] { const char* e = getenv("SCAT_WG_ROWS"); return e ? atoi(e) : 1; }();
     return m;
 }
 
+static bool rows64_shape(int Cin, int H, int W, int Cout) {
+    return Cin % 64 == 0 && Cout % 64 == 0 && W >= 7 && W <= 32 && H >= 2;
+}
+
 bool wgrad_rows_ok(int B, int Cin, int H, int W, int Cout, int KH, int stride, int pad, const void* dy, const void* x) {
-    return wg_rows_mode() && KH == 3 && stride == 1 && pad == 1 && Cin % 32 == 0 && Cout % 32 == 0 && Cin <= 64 &&
-           Cout <= 64 && W % 4 == 0 && W > 32 && W <= 64 && H >= 2 && (((uintptr_t)dy | (uintptr_t)x) & 15) == 0;
+    if (!(wg_rows_mode() && KH == 3 && stride == 1 && pad == 1 && (((uintptr_t)dy | (uintptr_t)x) & 15) == 0)) return false;
+    if (Cin % 32 == 0 && Cout % 32 == 0 && Cin <= 64 && Cout <= 64 && W % 4 == 0 && W > 32 && W <= 64 && H >= 2) return true;
+    if (!rows64_shape(Cin, H, W, Cout)) return false;
+    if (wg_rows_mode() & 2) return true;                       // SCAT_WG_ROWS=3: wherever the kernel can run (tests)
+    // measured at batch 96 (tools/conv_bench.py): ahead of the 128 x 128 producer/consumer kernel where a workgroup has
+    // enough rows to amortise its prologue and epilogue — 128 -> 128 @28 188 -> 157 us, 256 -> 256 @14 209 -> 178 us —
+    // behind it on 7 x 7 maps (7 of 16 pixels of a step are live) and on HRNet's small 64 / 128 / 256-channel branches
+    const int64_t cc = (int64_t)Cin * Cout;
+    return (W > 16 && cc >= 128 * 128) || (W > 8 && W <= 16 && cc >= 256 * 256);
 }
 
 static void rows_plan(int B, int Cin, int H, int W, int Cout, int& rpw, int& splits) {
-    const int rows = B * H, combos = (Cin / 32) * (Cout / 32);
-    const int noct = 2 * ((W + 15) / 16);
-    const int per_cu = noct > 4 ? 1 : 2;                       // workgroups a CU holds (LDS: 15 KB per octet)
+    const bool big = W <= 32;                                 // 64 x 64 blocks
+    const int rows = B * H, combos = big ? (Cin / 64) * (Cout / 64) : (Cin / 32) * (Cout / 32);
     static const int tgt = [] { const char* e = getenv("SCAT_WG_ROWS_TARGET"); return e ? atoi(e) : 0; }();
-    const int target = tgt > 0 ? tgt : 256 * per_cu;
+    const int target = tgt > 0 ? tgt : 256;                   // one workgroup per CU (LDS)
     int s = (target + combos - 1) / combos;
     rpw = (rows + s - 1) / s;
     if (rpw < 8) rpw = 8;
+    if (big && W <= 16) rpw = (rpw + 1) & ~1;                 // whole two-row groups
     if (rpw > rows) rpw = rows;
     splits = (rows + rpw - 1) / rpw;
 }
@@ -277,14 +502,36 @@ int64_t wgrad_rows_ws(int B, int Cin, int H, int W, int Cout) {
 // slab -> dw by launch_splitk_reduce (caller); returns the number of slabs
 int wgrad_rows_launch(const float* dy, const float* x, float* slab, int B, int Cin, int H, int W, int Cout,
                       const float* in_scale, const float* in_shift, int in_relu, hipStream_t st) {
+    int splits, rpw;
+    rows_plan(B, Cin, H, W, Cout, rpw, splits);
+    if (W <= 32) {
+        RowWg64Desc d{};
+        d.dy = dy; d.x = x; d.slab = slab; d.scale = in_scale; d.shift = in_shift; d.relu = in_scale ? in_relu : 0;
+        d.B = B; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.rows = B * H; d.rpw = rpw; d.ncb = Cin / 64;
+        d.noct = 2 * ((W + 15) / 16); d.nov = (W + 7) / 8;
+        d.dH = FastDiv::make(H);
+        d.ndy = (int64_t)B * Cout * H * W; d.nx = (int64_t)B * Cin * H * W;
+        const int rpi = W <= 16 ? 2 : 1;
+        d.rpi = rpi;
+        const size_t lds_bytes = (size_t)(4 * rpi * 3 + 2 * rpi * 9) * d.noct * 64 * 16;
+        static bool once1 = (hipFuncSetAttribute((const void*)wgrad3x3_rows64_kernel<1>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 30 * 4 * 64 * 16) == hipSuccess);
+        static bool once2 = (hipFuncSetAttribute((const void*)wgrad3x3_rows64_kernel<2>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 2 * 64 * 16) == hipSuccess);
+        (void)once1; (void)once2;
+        set_kernel_label("wgrad3x3_rows_64x576x16%s_r%d_split%d", in_scale ? "_tf" : "", rpi, splits);
+        const dim3 grid(d.ncb * (Cout / 64), 1, splits);
+        if (rpi == 2) hipLaunchKernelGGL(wgrad3x3_rows64_kernel<2>, grid, dim3(512), lds_bytes, st, d);
+        else hipLaunchKernelGGL(wgrad3x3_rows64_kernel<1>, grid, dim3(512), lds_bytes, st, d);
+        return splits;
+    }
     RowWgDesc d{};
     d.dy = dy; d.x = x; d.slab = slab; d.scale = in_scale; d.shift = in_shift; d.relu = in_scale ? in_relu : 0;
     d.B = B; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.rows = B * H; d.ncb = Cin / 32;
     d.noct = 2 * ((W + 15) / 16); d.nov = (W + 7) / 8;
     d.dH = FastDiv::make(H);
     d.ndy = (int64_t)B * Cout * H * W; d.nx = (int64_t)B * Cin * H * W;
-    int splits;
-    rows_plan(B, Cin, H, W, Cout, d.rpw, splits);
+    d.rpw = rpw;
     static const int stamp = [] { const char* e = getenv("SCAT_WG_ROWS_STAMP"); return e ? atoi(e) : 0; }();
     d.stamp = stamp;
     const size_t lds_bytes = (size_t)(4 * 3 + 2 * 9) * d.noct * 32 * 16;

@@ -1,6 +1,8 @@
 """Per-kernel parity on a real MI355X: every C-ABI op against the plain PyTorch fp32/fp64 CPU op
 it replaces, on seeded inputs. Tolerance (norm-wise relative, max|a-b|/max|b|): 2e-5 for
 contractions (fp32 fma chains in a different order), 1e-5 for element-wise / normalisation."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -99,6 +101,35 @@ def test_conv_fused_input_transform(ops):
 @pytest.mark.parametrize("B,cin,cout,H,W,tf", [(3, 32, 32, 20, 56, False), (2, 64, 64, 9, 44, True), (5, 32, 64, 7, 40, True),
                                                (2, 64, 32, 5, 52, False), (4, 32, 32, 2, 64, True), (7, 64, 64, 3, 36, False)])
 def test_wgrad3x3_rows(ops, B, cin, cout, H, W, tf):
+    _wgrad3x3_rows(ops, B, cin, cout, H, W, tf)
+
+
+ROWS64 = [(2, 64, 64, 9, 28, True), (3, 128, 64, 14, 14, False), (5, 64, 128, 7, 7, True), (2, 64, 64, 5, 32, False),
+          (3, 128, 128, 3, 20, True), (4, 64, 64, 2, 12, False), (9, 64, 64, 7, 7, False)]
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,tf", [(2, 128, 128, 9, 28, True), (3, 256, 256, 5, 14, False), (2, 128, 256, 3, 20, True)])
+def test_wgrad3x3_rows64(ops, B, cin, cout, H, W, tf):
+    """64 x 64 blocks on rows of at most 32 pixels (the shapes the default rule sends there); two rows per interval for
+    W <= 16, rows that are not 16-byte multiples."""
+    _wgrad3x3_rows(ops, B, cin, cout, H, W, tf)
+
+
+def test_wgrad3x3_rows64_every_shape():
+    """The same kernel forced onto the shapes the default rule leaves to the 128 x 128 kernel (SCAT_WG_ROWS=3, read once
+    per process, hence the child): odd row counts, image boundaries inside a row pair, 7-pixel rows."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_ops as T\nfrom scat_amd import ops\n"
+            "for a in T.ROWS64:\n    T._wgrad3x3_rows(ops, *a)\nprint('ROWS64 OK')\n") % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SCAT_WG_ROWS="3"), capture_output=True, text=True,
+                       timeout=300, cwd=root)
+    assert "ROWS64 OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def _wgrad3x3_rows(ops, B, cin, cout, H, W, tf):
     """The row-walking 3x3 weight gradient of the 32/64-channel layers (csrc/conv_wgrad_rows.hip): image borders,
     partial last octets (W % 8 == 4), three and four 16-pixel steps per row, workgroups whose row range starts / ends
     inside an image, fused input transform."""
