@@ -431,6 +431,10 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
+    // SCAT_TUNE=77 (timing experiments, tools/pw_stamp.py): thread 0 overwrites the tile's first 8 outputs with time stamps
+    const bool stamp = d.variant == 77;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (stamp) ts0 = __builtin_amdgcn_s_memrealtime();
     if constexpr (DS) {
         load_b(0, S0{});
         load_a(areg[0], 0);
@@ -462,6 +466,7 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
         store_b(0, Bs(0), S0{});
         __syncthreads();
         read_b(bfr[0], Bs(0), 0, 0);
+        if (stamp) ts1 = __builtin_amdgcn_s_memrealtime();
 
         // stage s: LDS buffer s & 1, register set s & 1 is free again (its data went to LDS one stage ago)
         auto stage = [&](int s, auto cur_tag) {
@@ -490,7 +495,20 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
             if (s + 1 < nstage) stage(s + 1, S1{});
         }
     }
+    if (stamp) ts2 = __builtin_amdgcn_s_memrealtime();
     store_tile<1, NI, BM, BN, WM, WN>(acc, dc, d.M, d.npix, i0, j0, 0);
+    if (stamp) {
+        __syncthreads();
+        if (tid == 0 && dc.mode == 1) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const uint32_t n = dc.dHW.div((uint32_t)j0);
+            const int hw = j0 - (int)n * dc.HW;
+            if (hw + 8 <= dc.HW && ((hw & 1) == 0)) {
+                unsigned long long* o = (unsigned long long*)(dc.p + ((int64_t)n * dc.C + i0) * dc.HW + hw);
+                o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memrealtime();
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------- producer / consumer wave specialisation
