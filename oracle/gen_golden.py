@@ -180,6 +180,51 @@ def g_encoder():
     np.savez(os.path.join(GOLD, "encoder.npz"), **out)
 
 
+def g_encoder_nope():
+    """hand_net.py:364-373 with pos_embed=False and masking on: ``feat`` is a view of ``feat_visual``, so the mask
+    token is written into the returned ``feat_visual`` and ``pl_term`` is taken at the post-write tensor."""
+    net, mp = _enc(pos_embed=False)
+    x = T(synth.images(52, 2))
+    random.seed(3)
+    net.train()
+    pred, fv, pl = net(x)
+    (pred * T(synth.normal_like(54, "cot", (2, 66)))).sum().backward()
+    out = {"pred": pred.detach().numpy(), "fv": digest(fv, 64), "pl": digest(pl, 64),
+           "fv_chsum": fv.detach().double().sum(dim=(0, 2, 3)).numpy(),
+           "pl_chsum": pl.detach().double().abs().sum(dim=(0, 2, 3)).numpy(),
+           "g_full:mask_token": net.mask_token.grad.numpy(),
+           "g_full:conv1x1_channel_reduction.weight": net.conv1x1_channel_reduction.weight.grad.numpy()}
+    np.savez(os.path.join(GOLD, "encoder_nope.npz"), **out)
+
+
+def g_h3dw():
+    """H3DWEncoder (hand_net.py:28-58; imported by eval.py:26), batch 1 (the only batch it runs at), eval and train."""
+    from models.hand_net import H3DWEncoder
+
+    mp = T(synth.normal_like(81, "mean61", (1, 61))) * 0.1
+    net = H3DWEncoder(opt_ns(), mp)
+    sd = {k: v for k, v in synth.to_torch(synth.encoder_transformer_state(81, 8)).items() if k.startswith("main_encoder.")}
+    for k, shp, s in (("feat_encoder.1.weight", (1024, 1024), 1024 ** -0.5), ("feat_encoder.1.bias", (1024,), 0.05),
+                      ("regressor.0.weight", (61, 1085), 1085 ** -0.5), ("regressor.0.bias", (61,), 0.05)):
+        sd[k] = T(synth.normal_like(82, k, shp)) * s
+    load_strict(net, sd)
+    x = T(synth.images(83, 1))
+    out = {"keys": np.array(list(net.state_dict().keys()))}
+    net.eval()
+    feat, pred = net(x)
+    out["eval:feat"] = feat.detach().numpy()
+    out["eval:pred"] = pred.detach().numpy()
+    net.train()
+    net.main_encoder.eval()       # batch-1 train-mode BatchNorm statistics of a 7x7 map are noise; keep them fixed
+    feat, pred = net(x)
+    (pred * T(synth.normal_like(84, "cot", (1, 61)))).sum().backward()
+    out["train:pred"] = pred.detach().numpy()
+    for k in ("feat_encoder.1.weight", "regressor.0.weight", "regressor.0.bias", "main_encoder.fc1.weight",
+              "main_encoder.layer4.2.conv3.weight"):
+        out["g:" + k] = digest(dict(net.named_parameters())[k].grad, 16)
+    np.savez(os.path.join(GOLD, "h3dw.npz"), **out)
+
+
 def g_trainstep():
     """G6: two full train steps (reference net + torch.optim.Adam + restated train.py loss)."""
     net, mp = _enc(seed=61)
@@ -420,7 +465,7 @@ def g_ckpt():
              digests=np.stack([digest(sd[k].float(), 4)[:4] for k in keys]))
 
 
-ALL = {"coarse": g_coarse, "hrnet": g_hrnet, "vt": g_vt, "bottleneck": g_bottleneck, "resnet": g_resnet, "encoder": g_encoder,
+ALL = {"encoder_nope": g_encoder_nope, "h3dw": g_h3dw, "coarse": g_coarse, "hrnet": g_hrnet, "vt": g_vt, "bottleneck": g_bottleneck, "resnet": g_resnet, "encoder": g_encoder,
        "trainstep": g_trainstep, "vit": g_vit, "performer": g_performer, "dp": g_dp, "metrics": g_metrics, "ckpt": g_ckpt}
 
 if __name__ == "__main__":

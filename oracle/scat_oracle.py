@@ -309,6 +309,11 @@ def encoder_transformer_forward(sd, mean_params, x, heads=8, iteration=3, pos_em
     if len(masked):
         feat = feat.clone()
         feat[:, masked, :] = sd["mask_token"]  # :373
+        if not pos_embed:
+            # :364 makes ``feat`` a VIEW of ``feat_visual`` and :367 is skipped, so the in-place write of :373 lands in
+            # the tensor the reference returns and :396 differentiates with respect to the post-write tensor
+            feat_visual = feat.view_as(feat_visual)
+            feat = feat_visual.view(b, 21, -1)
     feat_out = vt_forward(sd, feat, "transformer.", 3, heads, 64).reshape(b, -1)  # :375-377
     pred = mean_params.repeat(b, 1).clone()
     pred[:, 3:] = pred[:, 3:] + feat_out  # :383

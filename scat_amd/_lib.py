@@ -10,6 +10,13 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "scat_hip.h")
 LIBPATH = os.path.join(HERE, "libscat_hip.so")
+if os.environ.get("SCAT_LIBPATH"):
+    # measurement tools only (tools/pw_stamp.py, rows_stamp.py): the -DSCAT_DIAG build whose kernels can overwrite their
+    # outputs with time stamps.  Said loudly, because results from that library are not the product's.
+    import warnings
+
+    LIBPATH = os.path.abspath(os.environ["SCAT_LIBPATH"])
+    warnings.warn(f"scat_amd: SCAT_LIBPATH set, loading {LIBPATH} instead of the shipped libscat_hip.so", RuntimeWarning)
 
 _CT = {
     "int": ctypes.c_int,

@@ -22,7 +22,7 @@ def _sources():
 def _deps_mtime():
     m = 0.0
     for root, _, files in os.walk(CSRC):
-        if root.endswith("_obj"):
+        if root.endswith(("_obj", "_obj_diag")):
             continue
         for f in files:
             if f.endswith((".h", ".hip")):
@@ -31,8 +31,25 @@ def _deps_mtime():
     return m
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every .hip for gfx950 and link the shared library. Returns its path."""
+DIAG_OUT = os.path.join(HERE, "..", "tools", "_bin", "libscat_hip_diag.so")
+
+
+def build(force: bool = False, verbose: bool = True, diag: bool = False) -> str:
+    """Compile every .hip for gfx950 and link the shared library. Returns its path.
+    diag: the tools build (-DSCAT_DIAG: in-kernel time stamps, ablation and negative-result kernel variants) into
+    tools/_bin/libscat_hip_diag.so — never the library the boundary ships; tools select it with SCAT_LIBPATH."""
+    global OUT, OBJ
+    if diag:
+        out, obj, flags = os.path.abspath(DIAG_OUT), os.path.join(CSRC, "_obj_diag"), FLAGS + ["-DSCAT_DIAG"]
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        saved = (OUT, OBJ, list(FLAGS))
+        OUT, OBJ = out, obj
+        FLAGS[:] = flags
+        try:
+            return build(force, verbose, False)
+        finally:
+            OUT, OBJ = saved[0], saved[1]
+            FLAGS[:] = saved[2]
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _deps_mtime():
         return OUT
     os.makedirs(OBJ, exist_ok=True)
@@ -66,4 +83,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, diag="--diag" in sys.argv))

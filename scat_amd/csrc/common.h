@@ -8,6 +8,15 @@
 
 namespace scat {
 
+// Timing-experiment code (in-kernel time stamps that overwrite outputs, ablation variants) exists only in the
+// tools build (python -m scat_amd.build --diag -> tools/_bin/libscat_hip_diag.so, -DSCAT_DIAG): the shipped
+// library has no switch that changes results.
+#ifdef SCAT_DIAG
+constexpr bool kDiag = true;
+#else
+constexpr bool kDiag = false;
+#endif
+
 void set_error(const char* fmt, ...);
 void set_kernel_label(const char* fmt, ...);   // which engine instantiation the last call launched
 // scat_epilogue_stats_arm: the next contraction launched from this thread may write per-tile row sums into the armed

@@ -431,8 +431,8 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    // SCAT_TUNE=77 (timing experiments, tools/pw_stamp.py): thread 0 overwrites the tile's first 8 outputs with time stamps
-    const bool stamp = d.variant == 77;
+    // diag build only (SCAT_TUNE=77, tools/pw_stamp.py): thread 0 overwrites the tile's first 8 outputs with time stamps
+    const bool stamp = kDiag && d.variant == 77;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
     if (stamp) ts0 = __builtin_amdgcn_s_memrealtime();
     if constexpr (DS) {
@@ -1350,6 +1350,7 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
         if (pc < 0) pc = (cfg == 0 && M >= 256 && tiles(128, 128) >= 257 && tiles(128, 128) < 330) ? 6 : 0;
         // wide form: pointwise, whole pixel quads inside one image, 16-byte aligned planes, NCHW output
         const bool w4ok = HW % 4 == 0 && ((uintptr_t)dst & 15) == 0 && (!bias || dc.bias_mode == 1);
+#ifdef SCAT_DIAG     // negative results kept for A/B runs in the tools build only: barrier-free ring, 16x16x32 consumers
         if (cfg == 0 && pc == 8 && M >= 256) {
             set_kernel_label("conv1x1_split_pcring_256x128x32%s", in_scale ? "_tf" : "");
             if (in_scale) launch_pw_pc<1, true, 0, false, 8, false, 6>(d, dc, st);
@@ -1364,6 +1365,9 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
             SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
             return SCAT_OK;
         }
+#else
+        if (pc != 5 && pc != 6) pc = 0;      // the shipped library has the two forms the default rule picks, nothing else
+#endif
         if (cfg == 0 && (pc == 5 || pc == 6) && M >= 256) {
             const bool wide = pc == 6 && w4ok;
             set_kernel_label("conv1x1_split_pc%s256x128x32%s", wide ? "4_" : "8w_", in_scale ? "_tf" : "");
@@ -1375,10 +1379,12 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
             SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
             return SCAT_OK;
         }
+#ifdef SCAT_DIAG     // four-consumer producer/consumer forms: no gain over the plain kernel, tools build only
         if (cfg == 0 && pc >= 3 && pc <= 4 && w4ok) {
             const bool big = pc == 4 && M >= 256;
             set_kernel_label("conv1x1_split_pc4_%dx128x32%s", big ? 256 : 128, in_scale ? "_tf" : "");
-            if (!in_scale && !big && tuning() >= 100) {
+#ifdef SCAT_DIAG
+            if (!in_scale && !big && tuning() >= 100) {      // ablation variants (SCAT_TUNE=100+DIAG), diag build only
                 switch (tuning() - 100) {
                 case 1: launch_pw_pc<1, false, 1, true>(d, dc, st); break;
                 case 2: launch_pw_pc<1, false, 2, true>(d, dc, st); break;
@@ -1388,7 +1394,9 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
                 case 20: launch_pw_pc<1, false, 20, true>(d, dc, st); break;
                 default: launch_pw_pc<1, false, 0, true>(d, dc, st);
                 }
-            } else if (in_scale) {
+            } else
+#endif
+            if (in_scale) {
                 if (big) launch_pw_pc<2, true, 0, true>(d, dc, st); else launch_pw_pc<1, true, 0, true>(d, dc, st);
             } else {
                 if (big) launch_pw_pc<2, false, 0, true>(d, dc, st); else launch_pw_pc<1, false, 0, true>(d, dc, st);
@@ -1399,7 +1407,8 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
         if (cfg == 0 && pc && pc <= 4) {
             const bool big = (pc == 2 || pc == 4) && M >= 256;
             set_kernel_label("conv1x1_split_pc%dx128x32%s", big ? 256 : 128, in_scale ? "_tf" : "");
-            if (!in_scale && !big && tuning() >= 100) {      // timing experiments (SCAT_TUNE=100+DIAG)
+#ifdef SCAT_DIAG
+            if (!in_scale && !big && tuning() >= 100) {      // ablation variants (SCAT_TUNE=100+DIAG), diag build only
                 switch (tuning() - 100) {
                 case 1: launch_pw_pc<1, false, 1>(d, dc, st); break;
                 case 2: launch_pw_pc<1, false, 2>(d, dc, st); break;
@@ -1415,11 +1424,13 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
                 SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
                 return SCAT_OK;
             }
+#endif
             if (in_scale) { if (big) launch_pw_pc<2, true>(d, dc, st); else launch_pw_pc<1, true>(d, dc, st); }
             else { if (big) launch_pw_pc<2, false>(d, dc, st); else launch_pw_pc<1, false>(d, dc, st); }
             SCAT_LAUNCH_CHECK("scat_conv1x1_s1");
             return SCAT_OK;
         }
+#endif
         set_kernel_label("conv1x1_split_%sx32%s", names[cfg], in_scale ? "_tf" : "");
         if (in_scale) {
             if (cfg == 0) launch_pw_split<4, 128, true>(d, dc, st);

@@ -36,7 +36,7 @@ struct RowWgDesc {
     int nov;              // octets that hold pixels: ceil(W / 8)
     FastDiv dH;
     int64_t ndy, nx;
-    int stamp;            // timing experiments only (SCAT_WG_ROWS_STAMP): results are overwritten by time stamps
+    int stamp;            // diag build only (SCAT_WG_ROWS_STAMP, tools/rows_stamp.py): results are overwritten by time stamps
 };
 
 constexpr int RW_NT = 512;      // wavefronts 0-3: consumers (16-pixel step q = wavefront, all nine taps); 4-7: producers
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(RW_NT) void wgrad3x3_rows_kernel(RowWgDesc d) {
     const int N = d.Cin * 9;
 
     unsigned long long t0 = 0, t1 = 0, t2 = 0;
-    if (d.stamp) t0 = __builtin_amdgcn_s_memrealtime();
+    if (kDiag && d.stamp) t0 = __builtin_amdgcn_s_memrealtime();
     for (int i = tid; i < 4 * XS + 2 * DS; i += RW_NT) L[i] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
     if (g0 >= g1) return;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(RW_NT) void wgrad3x3_rows_kernel(RowWgDesc d) {
     }
     const int frag = lh * 32 + l31;
     __syncthreads();
-    if (d.stamp) t1 = __builtin_amdgcn_s_memrealtime();
+    if (kDiag && d.stamp) t1 = __builtin_amdgcn_s_memrealtime();
     for (int g = g0; g < g1; ++g) {
         for (int q = wave; q < ks; q += 4) {
             const u32x4* ds = DY + (g & 1) * DS + frag + q * 64;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(RW_NT) void wgrad3x3_rows_kernel(RowWgDesc d) {
         if (++y == d.H) y = 0;
         __syncthreads();
     }
-    if (d.stamp) t2 = __builtin_amdgcn_s_memrealtime();
+    if (kDiag && d.stamp) t2 = __builtin_amdgcn_s_memrealtime();
     // sum of the four wavefronts' tiles: 2 + 3 -> LDS -> 0 + 1, then 1 -> LDS -> 0 (9 tiles x 16 registers x 64 lanes)
     float* const R = lds;
     auto put = [&](int slot) {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(RW_NT) void wgrad3x3_rows_kernel(RowWgDesc d) {
                 }
     }
     __syncthreads();
-    if (d.stamp && tid == 0) {
+    if (kDiag && d.stamp && tid == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         unsigned long long* o64 = (unsigned long long*)(d.slab + ((int64_t)z * d.Cout + mb * 32) * N + cb * 288);
         o64[0] = t0; o64[1] = t1; o64[2] = t2; o64[3] = __builtin_amdgcn_s_memrealtime();
@@ -533,7 +533,7 @@ int wgrad_rows_launch(const float* dy, const float* x, float* slab, int B, int C
     d.ndy = (int64_t)B * Cout * H * W; d.nx = (int64_t)B * Cin * H * W;
     d.rpw = rpw;
     static const int stamp = [] { const char* e = getenv("SCAT_WG_ROWS_STAMP"); return e ? atoi(e) : 0; }();
-    d.stamp = stamp;
+    d.stamp = kDiag ? stamp : 0;
     const size_t lds_bytes = (size_t)(4 * 3 + 2 * 9) * d.noct * 32 * 16;
     static bool once = (hipFuncSetAttribute((const void*)wgrad3x3_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)((4 * 3 + 2 * 9) * 8 * 32 * 16)) == hipSuccess);

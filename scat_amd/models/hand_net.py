@@ -159,6 +159,49 @@ class _HeadLoopFn(torch.autograd.Function):
         return dfeat, None, dw, db, None
 
 
+class H3DWEncoder(nn.Module):
+    """models/hand_net.py:28-58 — the FrankMocap-style regressor ``eval.py:26`` imports: ResNet-50 feature →
+    ``relu, Linear(1024,1024), relu`` → 3 x ``Linear(1085 -> 61)`` residual steps from the mean parameters;
+    returns ``(feat, pred_params)``.  Like the reference it only runs at batch 1 (``torch.cat`` of ``feat[B,1024]``
+    with the un-repeated ``mean_params[1,61]``, hand_net.py:52-54); larger batches raise the same way."""
+
+    def __init__(self, opt, mean_params):
+        super().__init__()
+        self.mean_params = mean_params.clone().cuda()
+        self.total_params_dim = 61
+        self.feat_encoder = nn.Sequential(snn.ReLU(inplace=False), snn.Linear(1024, 1024), snn.ReLU(inplace=False))
+        self.regressor = nn.Sequential(snn.Linear(1024 + self.total_params_dim, self.total_params_dim))
+        self.main_encoder = get_model("resnet50")
+
+    def forward(self, main_input):
+        main_feat, _, _, _, _ = self.main_encoder(main_input)
+        feat = self.feat_encoder(main_feat)
+        if feat.size(0) != self.mean_params.size(0):
+            raise RuntimeError(
+                f"Sizes of tensors must match except in dimension 1. Expected size {feat.size(0)} but got size "
+                f"{self.mean_params.size(0)} for tensor number 1 in the list. (H3DWEncoder concatenates feat with "
+                "the un-repeated mean_params, models/hand_net.py:52-54: batch 1 only)")
+        lin = self.regressor[0]
+        pred_params = _HeadLoopFn.apply(feat, self.mean_params.reshape(-1), lin.weight, lin.bias, 3)
+        return feat, pred_params
+
+
+class EncoderTransformerInception(nn.Module):
+    """models/hand_net.py:87-146 — importable (``train_coarse.py:7`` imports the name) but not constructible: the
+    reference class is broken as shipped (``vision_transformer.Transformer`` halves the token width while the
+    regressor is sized for a width-preserving one: ``mat1 and mat2 shapes cannot be multiplied``), no
+    BASELINE config names it, and its Inception-v3 trunk (models/inception.py) is outside the hot path
+    (OUT OF SCOPE)."""
+
+    def __init__(self, opt, mean_params):
+        super().__init__()
+        raise NotImplementedError(
+            "EncoderTransformerInception (models/hand_net.py:87-146) is broken as shipped in the reference "
+            "(dim-halving transformer vs a Linear(196+61, 61) regressor) and its Inception-v3 trunk is out of "
+            "scope of the MI355X hot path; use EncoderTransformer / EncoderTransformerCoarse / "
+            "EncoderTransformerHRNet.")
+
+
 class EncoderTransformerHRNet(nn.Module):
     """models/hand_net.py:150-213.  As shipped the reference pairs this wrapper with the dim-HALVING
     ``vision_transformer.Transformer`` and a regressor sized for a dim-preserving one, which cannot run
@@ -234,10 +277,16 @@ class EncoderTransformerCoarse(nn.Module):
             tokens = _TokensFn.apply(feat_visual.view(B, 21, -1), pe, self.mask_token, midx)
             self.transformer._holder.want_tape = bool(self.pl)
             feat_out, attn = self.transformer(tokens, None)
+            aliased = pe is None and midx is not None     # hand_net.py:273-284, see EncoderTransformer._token_path
+            if aliased:
+                feat_visual = tokens.view_as(feat_visual)
             pl_term = None
             if self.pl:
                 dtok = self.transformer.input_grad(torch.ones_like(feat_out))
-                pl_term = ops.tokens_bwd(dtok.contiguous(), midx, want_dmask=False)[0].view_as(feat_visual)
+                if aliased:
+                    pl_term = dtok.contiguous().view_as(feat_visual)
+                else:
+                    pl_term = ops.tokens_bwd(dtok.contiguous(), midx, want_dmask=False)[0].view_as(feat_visual)
             return feat_visual, feat_out, attn, pl_term
 
         main_feat, (feat_visual, feat_out, attn, pl_term) = _backbone_with_tokens(self.main_encoder, main_input,
@@ -310,12 +359,22 @@ class EncoderTransformer(nn.Module):
         tokens = _TokensFn.apply(feat_visual.view(B, 21, -1), pe, self.mask_token, midx)
         self.transformer._holder.want_tape = bool(self.pl)
         feat_out = self.transformer(tokens, None)                             # [B,21,3]
+        # hand_net.py:364-373: without the positional table ``feat`` is a VIEW of ``feat_visual``, so the reference's
+        # in-place mask-token write lands in the tensor it returns, and ``autograd.grad(.., feat_visual)`` is then taken
+        # at the post-scatter tensor (non-zero in the masked channels).  Unreachable from the CLI (``type=bool`` makes
+        # ``--pos_embed False`` truthy, config.py:44) but kept: golden ``encoder_nope.npz``.
+        aliased = pe is None and midx is not None
+        if aliased:
+            feat_visual = tokens.view_as(feat_visual)
         pl_term = None
         if self.pl:
             # d sum(feat_out) / d feat_visual, no graph (hand_net.py:396): replay the mixer tape for the
             # input gradient only, then undo the token scatter.
             dtok = self.transformer.input_grad(torch.ones_like(feat_out))
-            pl_term = ops.tokens_bwd(dtok.contiguous(), midx, want_dmask=False)[0].view_as(feat_visual)
+            if aliased:
+                pl_term = dtok.contiguous().view_as(feat_visual)
+            else:
+                pl_term = ops.tokens_bwd(dtok.contiguous(), midx, want_dmask=False)[0].view_as(feat_visual)
         return feat_visual, feat_out, pl_term
 
     def forward(self, main_input):

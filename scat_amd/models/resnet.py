@@ -276,7 +276,9 @@ class _BlockFn(torch.autograd.Function):
             _NBT.clear()
         out = rec[10]
         if blk.training and any(ctx.needs_input_grad):
-            ctx.rec = rec[:10] + (None, rec[11])       # (the output itself is not needed: the backward reads its mask)
+            # the backward needs the output only for its sign: the 1-bit mask when bn_apply wrote one; on maps it
+            # cannot pack (H*W % 4 != 0, e.g. layer4's 7x7) there is no mask and the output itself must stay
+            ctx.rec = rec if rec[11] is None else rec[:10] + (None, rec[11])
             ctx.params = params
         else:
             ctx.rec = None

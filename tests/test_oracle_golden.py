@@ -267,3 +267,19 @@ def test_coarse(golden):
     assert rel_err(pred, g["pred"]) < 5e-6
     assert digest_err(digest(attn, 64), g["attn"]) < 5e-6
     assert digest_err(digest(pl, 64), g["pl"]) < 5e-5
+
+
+def test_oracle_feat_visual_aliasing_without_positional_table(golden):
+    """hand_net.py:364-373, pos_embed=False + masking: the oracle must return the post-write ``feat_visual`` and the
+    pose-length term taken there, like the real reference (golden encoder_nope)."""
+    g = golden("encoder_nope")
+    sd = synth.to_torch(synth.encoder_transformer_state(51, 8))
+    for p in O.trainable(sd).values():
+        p.requires_grad_(True)
+    random.seed(3)
+    pred, fv, pl = O.encoder_transformer_forward(sd, T(synth.mean_params(51)), T(synth.images(52, 2)),
+                                                 pos_embed=False)
+    assert rel_err(pred.detach(), g["pred"]) < 2e-6
+    assert digest_err(digest(fv, 64), g["fv"]) < 2e-6
+    assert digest_err(digest(pl, 64), g["pl"]) < 2e-5
+    assert rel_err(pl.double().abs().sum(dim=(0, 2, 3)), g["pl_chsum"]) < 2e-5

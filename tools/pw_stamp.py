@@ -2,6 +2,8 @@
 """SCAT_TUNE=77: where a tile of the pointwise split kernel spends its time (prologue / stage loop / epilogue)."""
 import os, sys
 os.environ["SCAT_TUNE"] = "77"
+# the stamps exist only in the diag build (python -m scat_amd.build --diag)
+os.environ.setdefault("SCAT_LIBPATH", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", "libscat_hip_diag.so"))
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scat_amd import ops

@@ -2,6 +2,8 @@
 """SCAT_WG_ROWS_STAMP=1: where the row-walking weight gradient spends its time (prologue / row loop / epilogue)."""
 import os, sys
 os.environ["SCAT_WG_ROWS_STAMP"] = "1"
+# the stamps exist only in the diag build (python -m scat_amd.build --diag)
+os.environ.setdefault("SCAT_LIBPATH", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", "libscat_hip_diag.so"))
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scat_amd import ops
