@@ -100,6 +100,20 @@ int64_t scat_conv1x1_s1_ws(int M, int C);
 int scat_conv1x1_s1(const float* src, const float* w, float* dst, int B, int C, int HW, int M, int transposed,
                     const float* bias, const float* in_scale, const float* in_shift, int in_relu, int accumulate,
                     void* ws, int64_t ws_bytes, int w_ready, void* stream);
+/* ---- persistent stream-K schedule for the pointwise kernels ----
+ * One tile per workgroup leaves the last round of a launch half empty at batch 96 (588 / 1 176 tiles of 128 x 128 on the
+ * 768 workgroup slots of the chip).  scat_streamk_arm(buf, bytes) before a call of scat_conv1x1_s1 / scat_conv1x1_s1_bnb
+ * lends its kernel a scratch buffer (scat_streamk_bytes(), 16-B aligned, zero-filled when first handed over, used by one
+ * stream at a time): the launch then runs as one persistent grid whose workgroups share the (tile, 32-channel stage)
+ * list equally and exchange the partial sums of split tiles through that buffer — deterministic (a tile's partial sums
+ * are added in a fixed order that depends on the shape only), same epilogues.  The arming is per host thread and is
+ * consumed by the next pointwise call whether or not it qualifies (>= 256 tiles, no taps, split products).
+ * scat_streamk_error(buf, bytes, stream) SYNCHRONISES the stream and reports whether a workgroup ever gave up waiting
+ * for a partial tile (a diagnostic for tests; the wait is bounded so a fault can not hang the queue).  No reference
+ * counterpart: scheduling of nn.Conv2d(k=1), models/resnet.py:65-72. */
+int64_t scat_streamk_bytes(void);
+int scat_streamk_arm(void* buf, int64_t bytes);
+int scat_streamk_error(const void* buf, int64_t bytes, void* stream);
 /* ---- prepared weights (split-operand products) ----
  * The five entry points above that take `w_ready` re-lay their weights into ws (three bf16 planes in MFMA operand
  * order) before their main kernel: one small launch per convolution and direction, 114 per ResNet-50 train step
@@ -290,6 +304,10 @@ int64_t scat_regressor_bwd_ws(int B, int F, int P, int iters);
  * out[B,66], gt3d[B,63] / gt2d[B,42] with row stride ld_gt; losses[3] = {loss, l3d, l2d}; dout[B,66]. */
 int scat_loss_fwd_bwd(const float* out, const float* gt3d, const float* gt2d, int ld_gt, float w3d, float w2d,
                       float* losses, float* dout, int B, void* stream);
+/* The pose-length regulariser as train.py:178-183 computes it from the network's third output pl_term[B,C,H,W]
+ * (hand_net.py:395-396; it has no graph, so no backward):  len[b] = sqrt(mean_c sum_hw pl^2), l_pl = mean_b (len[b] -
+ * 0.01 mean_b len)^2.  lens: B floats of scratch; l_pl: one float. */
+int scat_pose_length_term(const float* pl_term, float* lens, float* l_pl, int B, int C, int HW, void* stream);
 
 /* ---- Adam (torch.optim.Adam defaults, train.py:60): one launch over a flat parameter bucket ---- */
 int scat_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

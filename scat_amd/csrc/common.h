@@ -19,6 +19,7 @@ constexpr bool kDiag = false;
 
 void set_error(const char* fmt, ...);
 void set_kernel_label(const char* fmt, ...);   // which engine instantiation the last call launched
+void append_kernel_label(const char* suffix);
 // scat_epilogue_stats_arm: the next contraction launched from this thread may write per-tile row sums into the armed
 // buffer.  A launcher that supports it calls this with the rows and column groups of its grid: returns the buffer (and
 // records the group count for scat_epilogue_stats_groups) when one is armed and large enough, else nullptr.

@@ -13,6 +13,8 @@
 //
 // Replaces nn.Conv2d(k=1) and its input gradient as called at models/resnet.py:65-67,70-72,84-92 of the
 // reference (conv1/conv3 of every Bottleneck) and the 1x1 reductions of models/hand_net.py, fp32.
+#include <atomic>
+
 #include "conv_common.h"
 #include "split.h"
 
@@ -225,8 +227,13 @@ __global__ __launch_bounds__(NT, (BM * BN >= 128 * 128 ? 2 : 3)) void conv1x1_ke
 // the epilogue never stores it), so the staging VALU carries no masks at all.  Beside a busy matrix pipe a SIMD issues
 // about one vector instruction per MFMA (tools/mfma_probe.hip, PROBE_PC=1): every instruction taken out of the staging
 // is time given back to the MFMAs.
-template <int WM, int BN, bool TF, bool DS = false, bool STEM = false, bool PL = false>
-__global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc dc) {
+//
+// pw_split_tile: the contraction stages [s_begin, s_end) of one output tile (a whole tile for the one-tile-per-workgroup
+// kernel; a K-segment of it for the persistent stream-K kernel below).  `post(acc)` runs on the finished accumulators
+// and says whether the epilogue (store_tile) follows.
+template <int WM, int BN, bool TF, bool DS, bool STEM, bool PL, class Post>
+__device__ __forceinline__ void pw_split_tile(const PwDesc& d, const OutDesc& dc, const int tile, const int s_begin,
+                                              const int s_end, Post post) {
     static_assert(!(TF && DS), "one input transform at a time");
     static_assert(!(PL && STEM), "the stem has its own staging");
     static_assert(!STEM || (!TF && !DS), "the stem reads the raw image");
@@ -236,14 +243,13 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
     extern __shared__ __align__(16) float lds[];      // B[2][3 planes][4 k-octets][BN] x 16 bytes
     auto Bs = [&](int buf) -> u32x4* { return (u32x4*)lds + buf * (12 * BN); };
 
-    const int mt = (d.M + BM - 1) / BM, nt = (d.npix + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int mt = (d.M + BM - 1) / BM;
     const int i0 = (tile % mt) * BM, j0 = (tile / mt) * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
     const int nsc = (d.C + PW_KS - 1) / PW_KS;       // 32-channel stages per tap
-    const int nstage = d.ntap * nsc;                   // contraction order: (tap, channel)
+    const int nstage = s_end;                          // contraction order: (tap, channel); loads past s_end read zeros
 
     // ---- activation staging: this thread's pixel, k-octets g0 + r*(NT/BN)
     const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(d.src, d.nsrc);
@@ -436,14 +442,14 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
     if (stamp) ts0 = __builtin_amdgcn_s_memrealtime();
     if constexpr (DS) {
-        load_b(0, S0{});
-        load_a(areg[0], 0);
-        store_b(0, Bs(0), S0{});
+        load_b(s_begin, S0{});
+        load_a(areg[0], 2 * s_begin);
+        store_b(s_begin, Bs(0), S0{});
         __syncthreads();
         read_b(bfr[0], Bs(0), 0, 0);
-        for (int s = 0; s < nstage; ++s) {
-            const u32x4* bcur = Bs(s & 1);
-            u32x4* bnext = Bs((s + 1) & 1);
+        for (int s = s_begin; s < nstage; ++s) {
+            const u32x4* bcur = Bs((s - s_begin) & 1);
+            u32x4* bnext = Bs((s - s_begin + 1) & 1);
             load_b(s + 1, S0{});
             static_for<2 * NI>([&](auto i_tag) {
                 constexpr int I = decltype(i_tag)::value, t = I / NI, b = I % NI;
@@ -460,10 +466,10 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
             read_b(bfr[0], bnext, 0, 0);
         }
     } else {
-        load_b(0, S0{});
-        load_b(1, S1{});
-        load_a(areg[0], 0);
-        store_b(0, Bs(0), S0{});
+        load_b(s_begin, S0{});
+        load_b(s_begin + 1, S1{});
+        load_a(areg[0], 2 * s_begin);
+        store_b(s_begin, Bs(0), S0{});
         __syncthreads();
         read_b(bfr[0], Bs(0), 0, 0);
         if (stamp) ts1 = __builtin_amdgcn_s_memrealtime();
@@ -490,12 +496,13 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
             __syncthreads();
             read_b(bfr[0], bnext, 0, 0);
         };
-        for (int s = 0; s < nstage; s += 2) {
+        for (int s = s_begin; s < nstage; s += 2) {
             stage(s, S0{});
             if (s + 1 < nstage) stage(s + 1, S1{});
         }
     }
     if (stamp) ts2 = __builtin_amdgcn_s_memrealtime();
+    if (!post(acc)) return;
     store_tile<1, NI, BM, BN, WM, WN>(acc, dc, d.M, d.npix, i0, j0, 0);
     if (stamp) {
         __syncthreads();
@@ -508,6 +515,125 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
                 o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memrealtime();
             }
         }
+    }
+}
+
+// one tile per workgroup, XCD-aware tile order
+template <int WM, int BN, bool TF, bool DS = false, bool STEM = false, bool PL = false>
+__global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc dc) {
+    constexpr int BM = 32 * WM;
+    const int mt = (d.M + BM - 1) / BM, nt = (d.npix + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int nstage = d.ntap * ((d.C + PW_KS - 1) / PW_KS);
+    pw_split_tile<WM, BN, TF, DS, STEM, PL>(d, dc, tile, 0, nstage, [](auto&) { return true; });
+}
+
+// ---------------------------------------------------------------- persistent stream-K schedule
+//
+// At batch 96 the tile counts of this network are multiples of 147 (96 * 49 * 2^k / 128): 588 or 1 176 tiles on the
+// 768 workgroup slots of the chip (256 CUs x 3) — the last round of a one-tile-per-workgroup grid is half empty, and
+// in-kernel time stamps (tools/pw_stamp.py) show the stage loop itself already saturates the matrix pipe.  Here the grid
+// IS the slot count: the tiles x stages of a launch are one list of (tile, stage) units, cut into equal contiguous
+// ranges, one per workgroup (Osama et al., "Stream-K", PPoPP'23).  A range is at most: the tail of a tile, whole tiles,
+// the head of a tile.
+//   * XCD-aware: hardware deals workgroup b to XCD b % 8.  Each XCD gets a contiguous chunk of whole tiles (as xcd_remap
+//     does) and its G / 8 workgroups stream over that chunk only, so a split tile's two halves, its weights and its
+//     activation panel stay in one L2.
+//   * A workgroup walks its range from the END: the head segment of its last tile comes first — its accumulators go to
+//     the workgroup's slot of the scratch buffer and a flag is raised — and the tail segment of its first tile comes
+//     last: the workgroup that holds a tile's tail owns the tile, adds the partial sums of its predecessors (in
+//     descending workgroup order: the result depends on the shape only, bit for bit reproducible) and runs the epilogue
+//     (bias / accumulate / BatchNorm sums unchanged: they see the complete accumulators).
+//   * An owner only ever waits for workgroups with a LOWER block index on the same XCD, whose partial was the first
+//     thing they did: hardware dispatches blocks in index order, so the wait can not deadlock whatever else occupies
+//     the GPU, and in practice never spins.  The spin is bounded all the same; exhaustion raises a sticky device-side
+//     error word (scat_device_error) instead of hanging the queue.
+//   * Partials and flags are written and read with agent-coherent (sc1) accesses: correct even if the two workgroups
+//     did not share an L2, and no L2 write-back fence (buffer_wbl2) anywhere.
+struct SkDesc {
+    float* part;          // [G][BM * BN] accumulator images in fragment order
+    uint32_t* flags;      // [G]: == id once the workgroup's partial is complete
+    uint32_t* err;        // sticky error word
+    uint32_t id;          // unique per launch (the scratch buffer is recycled between launches)
+    int G;                // workgroups = slots, multiple of 8
+    int coh;              // 1: partials through agent-coherent (sc1, write-through) accesses; 0: through the XCD's L2
+};
+
+template <int WM, int BN, bool TF, bool DS = false, bool PL = true>
+__global__ __launch_bounds__(NT, 3) void conv1x1_sk_kernel(PwDesc d, OutDesc dc, SkDesc sk) {
+    constexpr int BM = 32 * WM, WN = 4 / WM, NI = BN / (32 * WN);
+    const int mt = (d.M + BM - 1) / BM, nt = (d.npix + BN - 1) / BN;
+    const int T = mt * nt;
+    const int nstage = d.ntap * ((d.C + PW_KS - 1) / PW_KS);
+    const int x = blockIdx.x & 7, s = blockIdx.x >> 3, Gx = sk.G >> 3;
+    const int q = T >> 3, r = T & 7;
+    const int t0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;      // this XCD's tiles: [t0, t0 + tcount)
+    const int tcount = q + (x < r ? 1 : 0);
+    const int64_t U = (int64_t)tcount * nstage;
+    auto ubeg = [&](int w) { return (int)((int64_t)w * U / Gx); };      // unit range of workgroup w of this XCD
+    const int u0 = ubeg(s), u1 = ubeg(s + 1);
+    const int tid = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t rp = make_rsrc(sk.part, (int64_t)sk.G * BM * BN);
+    constexpr int SC1 = 16;                                                // agent-coherent cache policy (gfx940+)
+
+    for (int u = u1; u > u0;) {
+        const int tl = (u - 1) / nstage;                                   // local tile of the range's last unit
+        const int ua = tl * nstage;
+        const int a = (u0 > ua ? u0 : ua) - ua, e = u - ua;                // stages [a, e) of that tile
+        u = ua + a;
+        pw_split_tile<WM, BN, TF, DS, false, PL>(d, dc, t0 + tl, a, e, [&](f32x16 (&acc)[1][NI]) {
+            if (a == 0 && e == nstage) return true;                        // a whole tile: nothing to exchange
+            if (e != nstage) {
+                // head (or middle) segment: publish the partial sums
+                const int slot = (x * Gx + s) * (BM * BN * 4);
+#pragma unroll
+                for (int b = 0; b < NI; ++b)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        u32x4 v = {__float_as_uint(acc[0][b][4 * k]), __float_as_uint(acc[0][b][4 * k + 1]),
+                                   __float_as_uint(acc[0][b][4 * k + 2]), __float_as_uint(acc[0][b][4 * k + 3])};
+                        if (sk.coh) __builtin_amdgcn_raw_buffer_store_b128(v, rp, ((b * 4 + k) * NT + tid) * 16, slot, SC1);
+                        else __builtin_amdgcn_raw_buffer_store_b128(v, rp, ((b * 4 + k) * NT + tid) * 16, slot, 0);
+                    }
+                __builtin_amdgcn_s_waitcnt(0);                             // this thread's stores have been acknowledged
+                __syncthreads();                                           // ... every thread's
+                if (tid == 0) __hip_atomic_store(sk.flags + x * Gx + s, sk.id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+            // tail segment: this workgroup owns the tile — add the predecessors' partial sums, nearest first
+            for (int w = s - 1; w >= 0; --w) {
+                if (ubeg(w) == ubeg(w + 1)) continue;                      // an empty range publishes nothing
+                if (tid == 0) {
+                    int spins = 0;
+                    while (__hip_atomic_load(sk.flags + x * Gx + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.id) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > (1 << 22)) {                         // seconds: something is badly wrong
+                            __hip_atomic_store(sk.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                __syncthreads();
+                const int slot = (x * Gx + w) * (BM * BN * 4);
+#pragma unroll
+                for (int b = 0; b < NI; ++b) {
+                    u32x4 v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        v[k] = sk.coh ? __builtin_amdgcn_raw_buffer_load_b128(rp, ((b * 4 + k) * NT + tid) * 16, slot, SC1)
+                                      : __builtin_amdgcn_raw_buffer_load_b128(rp, ((b * 4 + k) * NT + tid) * 16, slot, 1);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        acc[0][b][4 * k] += __uint_as_float(v[k].x);
+                        acc[0][b][4 * k + 1] += __uint_as_float(v[k].y);
+                        acc[0][b][4 * k + 2] += __uint_as_float(v[k].z);
+                        acc[0][b][4 * k + 3] += __uint_as_float(v[k].w);
+                    }
+                }
+                if (ubeg(w) <= ua) break;                                  // that one started the tile
+            }
+            return true;
+        });
     }
 }
 
@@ -1073,6 +1199,32 @@ static int pw_plain_mode() {
     return m;
 }
 
+// stream-K scratch armed by the caller for the next pointwise launch of this host thread (scat_streamk_arm)
+struct SkScratch { void* buf; int64_t bytes; };
+static thread_local SkScratch g_sk = {nullptr, 0};
+constexpr int SK_G = 768;                             // 256 CUs x 3 workgroups (48 KB of LDS, <= 170 VGPRs each)
+constexpr int64_t SK_PART = (int64_t)SK_G * 128 * 128 * 4;
+constexpr int64_t SK_BYTES = SK_PART + SK_G * 4 + 64;
+static std::atomic<uint32_t> g_sk_id{1};
+static int sk_mode() { return 1; }      // (the caller decides by arming a scratch buffer or not: ops.STREAMK)
+struct SkDisarm { ~SkDisarm() { g_sk.buf = nullptr; g_sk.bytes = 0; } };
+static bool sk_take(SkDesc& sk) {
+    void* b = g_sk.buf;
+    const int64_t n = g_sk.bytes;
+    g_sk.buf = nullptr;
+    g_sk.bytes = 0;
+    if (!b || n < SK_BYTES || ((uintptr_t)b & 15)) return false;
+    sk.part = (float*)b;
+    sk.flags = (uint32_t*)((char*)b + SK_PART);
+    sk.err = sk.flags + SK_G;
+    sk.id = g_sk_id.fetch_add(1, std::memory_order_relaxed);
+    if (sk.id == 0) sk.id = g_sk_id.fetch_add(1, std::memory_order_relaxed);   // 0 is what a fresh buffer holds
+    sk.G = SK_G;
+    static const int coh = [] { const char* e = getenv("SCAT_SK_COH"); return e ? atoi(e) : 1; }();
+    sk.coh = coh;
+    return true;
+}
+
 template <int WM, int BN, bool TF, bool DS = false, bool STEM = false>
 static void launch_pw_split(const PwDesc& d, const OutDesc& dc_in, hipStream_t st) {
     constexpr int BM = 32 * WM;
@@ -1082,6 +1234,15 @@ static void launch_pw_split(const PwDesc& d, const OutDesc& dc_in, hipStream_t s
     if (!dc.accumulate && !dc.bias) {                 // a forward convolution: its BatchNorm's sums ride in the epilogue
         dc.sg = nt * (4 / WM);
         dc.stats = epi_stats_take(d.M, dc.sg);
+    }
+    if constexpr (!STEM && BN == 128) {
+        // persistent stream-K grid when the caller armed a scratch buffer and the launch has enough tiles to share out
+        SkDesc sk{};
+        if (d.ntap == 1 && d.C % 32 == 0 && pw_plain_mode() && sk_mode() && (int64_t)mt * nt >= 256 && sk_take(sk)) {
+            hipLaunchKernelGGL((conv1x1_sk_kernel<WM, BN, TF, DS>), dim3(SK_G), dim3(NT), lds_bytes, st, d, dc, sk);
+            append_kernel_label("_sk");
+            return;
+        }
     }
     if constexpr (!STEM) {
         if (d.ntap == 1 && d.C % 32 == 0 && pw_plain_mode()) {
@@ -1260,6 +1421,7 @@ extern "C" int scat_conv7x7_s2_fwd_split(const float* x, const float* w, float* 
 extern "C" int scat_conv1x1_s1_bnb(const float* g, const float* z, const float* coef3, const float* w, float* dx, int B,
                                    int Cin, int HW, int Cout, int accumulate, void* ws, int64_t ws_bytes,
                                    int w_ready, void* stream) {
+    SkDisarm sk_guard;
     SCAT_REQUIRE(g && z && coef3 && w && dx, SCAT_E_ARG, "scat_conv1x1_s1_bnb: null pointer");
     SCAT_REQUIRE(math_mode() == 1, SCAT_E_ARG, "scat_conv1x1_s1_bnb: needs the split-operand product mode");
     SCAT_REQUIRE(B > 0 && Cin > 0 && HW > 0 && Cout > 0 && Cout % 16 == 0, SCAT_E_SHAPE,
@@ -1302,6 +1464,7 @@ extern "C" int64_t scat_conv1x1_s1_ws(int M, int C) { return (int64_t)M * ((C + 
 extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int B, int C, int HW, int M,
                                int transposed, const float* bias, const float* in_scale, const float* in_shift,
                                int in_relu, int accumulate, void* ws, int64_t ws_bytes, int w_ready, void* stream) {
+    SkDisarm sk_guard;      // an armed stream-K scratch is this call's or nobody's
     SCAT_REQUIRE(src && w && dst, SCAT_E_ARG, "scat_conv1x1_s1: null pointer");
     SCAT_REQUIRE(!w_ready || math_mode() == 1, SCAT_E_ARG, "scat_conv1x1_s1: prepared weights exist for split products only");
     SCAT_REQUIRE(ws && ws_bytes >= scat_conv1x1_s1_ws(M, C), SCAT_E_WORKSPACE, "scat_conv1x1_s1: workspace too small");
@@ -1533,5 +1696,25 @@ extern "C" int scat_transpose2d(const float* src, float* dst, int R, int C, void
     hipLaunchKernelGGL(transpose2d_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, (hipStream_t)stream, src, dst,
                        R, C);
     SCAT_LAUNCH_CHECK("scat_transpose2d");
+    return SCAT_OK;
+}
+
+/* Stream-K scratch for the pointwise kernels (include/scat_hip.h).  Consumed by the next qualifying launch of this host
+ * thread; a launch that does not qualify (few tiles, taps, scratch too small) disarms it and runs one tile per
+ * workgroup. */
+extern "C" int64_t scat_streamk_bytes(void) { return scat::SK_BYTES; }
+extern "C" int scat_streamk_arm(void* buf, int64_t bytes) {
+    scat::g_sk.buf = buf;
+    scat::g_sk.bytes = buf ? bytes : 0;
+    return SCAT_OK;
+}
+extern "C" int scat_streamk_error(const void* buf, int64_t bytes, void* stream) {
+    SCAT_REQUIRE(buf && bytes >= scat::SK_BYTES, SCAT_E_ARG, "scat_streamk_error: not a stream-K scratch buffer");
+    uint32_t v = 0;
+    hipError_t e = hipMemcpyAsync(&v, (const char*)buf + scat::SK_PART + scat::SK_G * 4, 4, hipMemcpyDeviceToHost,
+                                  (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    SCAT_REQUIRE(e == hipSuccess, SCAT_E_LAUNCH, "scat_streamk_error: %s", hipGetErrorString(e));
+    SCAT_REQUIRE(v == 0, SCAT_E_LAUNCH, "a stream-K workgroup gave up waiting for a partial tile (device error word %u)", v);
     return SCAT_OK;
 }

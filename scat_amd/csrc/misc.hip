@@ -27,6 +27,11 @@ void set_kernel_label(const char* fmt, ...) {
     va_end(ap);
 }
 
+void append_kernel_label(const char* suffix) {
+    const size_t n = strlen(g_label);
+    if (n + strlen(suffix) + 1 <= sizeof(g_label)) strcpy(g_label + n, suffix);
+}
+
 struct EpiStats { float* buf; int64_t cap; int groups; };
 static thread_local EpiStats g_epi = {nullptr, 0, 0};
 float* epi_stats_take(int rows, int groups) {
@@ -413,6 +418,51 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out
     }
 }
 
+// ---------------------------------------------------------------- pose-length term (train.py:178-183)
+//
+//   pl_lengths[b] = sqrt( mean_c sum_{h,w} pl_term[b,c,h,w]^2 );  pl_mean = 0.01 * mean_b pl_lengths;
+//   l_pl = mean_b (pl_lengths[b] - pl_mean)^2
+// Two launches instead of a dozen torch reductions: one workgroup per image (fp64 partial sums, fixed order), then one
+// wavefront-sized finish.  pl_term has no graph (hand_net.py:396), so there is no backward.
+__global__ __launch_bounds__(256) void pl_lengths_kernel(const float* __restrict__ pl, float* __restrict__ lens, int C,
+                                                         int HW) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int64_t n = (int64_t)C * HW;
+    const float* p = pl + blockIdx.x * n;
+    double s = 0;
+    if ((n & 3) == 0 && (((uintptr_t)p) & 15) == 0) {
+        for (int64_t e = tid * 4ll; e < n; e += 1024) {
+            const float4 v = *(const float4*)(p + e);
+            s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+    } else {
+        for (int64_t e = tid; e < n; e += 256) s += (double)p[e] * p[e];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) lens[blockIdx.x] = (float)sqrt((red[0] + red[1] + red[2] + red[3]) / C);
+}
+
+__global__ __launch_bounds__(64) void pl_finish_kernel(const float* __restrict__ lens, float* __restrict__ out, int B) {
+    const int tid = threadIdx.x;
+    double s = 0;
+    for (int b = tid; b < B; b += 64) s += lens[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float pl_mean = 0.01f * (float)(s / B);
+    double q = 0;
+    for (int b = tid; b < B; b += 64) {
+        const float dlt = lens[b] - pl_mean;
+        q += (double)dlt * dlt;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (tid == 0) out[0] = (float)(q / B);
+}
+
 // ---------------------------------------------------------------- Adam
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -615,6 +665,14 @@ extern "C" int scat_loss_fwd_bwd(const float* out, const float* gt3d, const floa
     hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, gt3d, gt2d, ld_gt, w3d, w2d,
                        losses, dout, B);
     SCAT_LAUNCH_CHECK("scat_loss_fwd_bwd");
+    return SCAT_OK;
+}
+
+extern "C" int scat_pose_length_term(const float* pl_term, float* lens, float* l_pl, int B, int C, int HW, void* stream) {
+    SCAT_REQUIRE(pl_term && lens && l_pl && B > 0 && C > 0 && HW > 0, SCAT_E_ARG, "scat_pose_length_term: bad argument");
+    hipLaunchKernelGGL(pl_lengths_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pl_term, lens, C, HW);
+    hipLaunchKernelGGL(pl_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lens, l_pl, B);
+    SCAT_LAUNCH_CHECK("scat_pose_length_term");
     return SCAT_OK;
 }
 

@@ -32,6 +32,20 @@ import torch.distributed as dist
 def _dp_check():
     return os.environ.get("SCAT_DP_CHECK", "0") != "0"
 
+
+# SCAT_DP_FORCE_COLLECTIVES=1: take the world > 1 code path (replica broadcast, ReduceOp.AVG probe, asynchronous
+# all-reduce per bucket on the ordering stream, work.wait() on the optimiser stream) even in a ONE-rank process group —
+# how the RCCL branch is exercised on a one-GPU box (tests/test_gpu_dp.py::test_rccl_single_rank_collectives).
+def _force_collectives():
+    return os.environ.get("SCAT_DP_FORCE_COLLECTIVES", "0") != "0"
+
+
+# The host driver of this pool only supports dmabuf IPC: RCCL's peer mappings over xGMI fail with "hipIpcGetMemHandle:
+# invalid argument" without this, and it has to be in the environment BEFORE HIP initialises — i.e. before the model's
+# constructor calls .cuda() (hand_net.py:321), which in the unattended path (auto_attach, from the first forward) is long
+# past.  Importing the package is the earliest point this library controls.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 _PRODUCERS: List = []   # streams other than the caller's on which gradient kernels run (process-wide)
 
 
@@ -89,7 +103,10 @@ class GradBuckets:
         self.head_params = [p for _, p in groups["head"]]
         self.bucket_params = {b: [p for _, p in items] for b, items in groups.items()}
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        have_pg = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if have_pg else 1
+        # collectives are issued when there is somebody to talk to — or when asked to rehearse them in a 1-rank group
+        self.collective = self.world > 1 or (have_pg and _force_collectives())
         self._pending = []
         self._head_sent = False
         self._sent = set()
@@ -99,7 +116,7 @@ class GradBuckets:
         self._host_stage = {}
         self.check = _dp_check()
         self._avg_ok = False
-        if self.world > 1:
+        if self.collective:
             self._sync_replicas(model)
             self._avg_ok = self._probe_avg()
         backbone = getattr(model, "main_encoder", None)
@@ -220,7 +237,7 @@ class GradBuckets:
 
     # ---- collectives
     def _allreduce(self, t, name="?"):
-        if self.world <= 1:
+        if not self.collective:
             if self.check:
                 self._checks.append((name, torch.isnan(t).any()))
             return
@@ -351,11 +368,6 @@ class GradBuckets:
 
 def init_distributed():
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run)."""
-    import os
-
-    # the host driver of this pool only supports dmabuf IPC: RCCL's peer mappings over xGMI fail with
-    # "hipIpcGetMemHandle: invalid argument" without it (must be in the environment before HIP initialises)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -364,7 +376,7 @@ def init_distributed():
         # 1-GPU box with the gloo backend maps every rank onto the one device)
         local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = os.environ.get("SCAT_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
@@ -388,6 +400,13 @@ def auto_attach(model):
         return
     if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
         return
+    if (torch.cuda.is_available() and torch.cuda.is_initialized() and not dist.is_initialized()
+            and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0"):
+        import warnings
+
+        warnings.warn("scat_amd.dp: HIP was initialised with HSA_ENABLE_IPC_MODE_LEGACY != 0; on hosts whose driver "
+                      "only supports dmabuf IPC RCCL then fails with 'hipIpcGetMemHandle: invalid argument' — export "
+                      "HSA_ENABLE_IPC_MODE_LEGACY=0 in the launcher", RuntimeWarning)
     init_distributed()
     model._dp_buckets = GradBuckets(model)
     model._dp_buckets.enable_auto()

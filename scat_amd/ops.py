@@ -232,6 +232,31 @@ def _pw_ok(KH, KW, stride, pad, csrc, *ts):
             and all(t is None or t.data_ptr() % 16 == 0 for t in ts))
 
 
+# Persistent stream-K grid for the pointwise kernels (csrc/conv1x1.hip conv1x1_sk_kernel).  OFF by default: measured at
+# batch 96 (profiles/r03_streamk.txt) it is 5-15 % SLOWER than one tile per workgroup on every ResNet-50 shape — the
+# hardware's dynamic dispatch already balances the tiles, and what the half-empty last round loses is less than the extra
+# prologues and the partial-tile exchange cost.  SCAT_SK=1 enables it (tests do, to keep the kernel honest).
+STREAMK = os.environ.get("SCAT_SK", "0") != "0"
+_sk_bufs = {}
+
+
+def _sk_arm(device):
+    """lend the next pointwise launch this stream's stream-K scratch (include/scat_hip.h scat_streamk_arm)"""
+    if not STREAMK:
+        return
+    key = (device.type, device.index, _stream())
+    buf = _sk_bufs.get(key)
+    if buf is None:
+        buf = _sk_bufs[key] = torch.zeros(int(lib().scat_streamk_bytes()), dtype=torch.uint8, device=device)
+    lib().scat_streamk_arm(_p(buf), buf.numel())
+
+
+def streamk_check():
+    """synchronise and raise if any stream-K launch of this process gave up waiting for a partial tile (tests)"""
+    for (_, _, st), buf in _sk_bufs.items():
+        lib().scat_streamk_error(_p(buf), buf.numel(), st)
+
+
 EPI_STATS = os.environ.get("SCAT_EPI_STATS", "1") != "0"   # BatchNorm sums in the convolution epilogue (0: separate pass)
 
 
@@ -270,6 +295,7 @@ def _conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, 
     y = out if out is not None else torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
     if _pw_ok(KH, KW, stride, pad, Cin, x, w, in_scale, in_shift):
         ws, rdy = _wp_ws(wp, w, WPREP_CONV1X1_FWD, Cout, Cin, 1, 1, 0, lib().scat_conv1x1_s1_ws(Cout, Cin), x.device)
+        _sk_arm(x.device)
         _prof(2.0 * B * OH * OW * Cout * Cin, lib().scat_conv1x1_s1, _p(x), _p(w), _p(y), B, Cin, H * W, Cout, 0,
               _p(bias), _p(in_scale), _p(in_shift), int(in_relu), 0, _p(ws), ws.numel(), rdy, _stream())
         return y
@@ -342,6 +368,7 @@ def conv2d_dgrad_w(dy, w, x_shape, stride, pad, out=None, accumulate=False, wp=N
     if _pw_ok(KH, KW, stride, pad, Cout, dy, w, out):
         dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
         ws, rdy = _wp_ws(wp, w, WPREP_CONV1X1_DGRAD, Cout, Cin, 1, 1, 0, lib().scat_conv1x1_s1_ws(Cin, Cout), dy.device)
+        _sk_arm(dy.device)
         _prof(2.0 * B * H * W * Cout * Cin, lib().scat_conv1x1_s1, _p(dy), _p(w), _p(dx), B, Cout, H * W, Cin, 1, 0, 0,
               0, 0, int(accumulate), _p(ws), ws.numel(), rdy, _stream())
         return dx
@@ -542,6 +569,7 @@ def conv1x1_dgrad_bnb(g, z, coef3, w, x_shape, out=None, accumulate=False, wp=No
     Cout = w.shape[0]
     dx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=g.device)
     ws, rdy = _wp_ws(wp, w, WPREP_CONV1X1_DGRAD, Cout, Cin, 1, 1, 0, lib().scat_conv1x1_s1_ws(Cin, Cout), g.device)
+    _sk_arm(g.device)
     _prof(2.0 * B * H * W * Cout * Cin, lib().scat_conv1x1_s1_bnb, _p(g), _p(z), _p(coef3), _p(w), _p(dx), B, Cin, H * W,
           Cout, int(accumulate), _p(ws), ws.numel(), rdy, _stream())
     return dx
@@ -827,6 +855,16 @@ def regressor_bwd(dout, feat, preds, w, iters, root_relative=True, want_dfeat_ou
     lib().scat_regressor_bwd(_p(dout), _p(feat), _p(preds), _p(w), _p(dfeat), _p(dfeat_out), _p(dw), _p(dbias), B, F,
                              P, iters, int(root_relative), _p(ws), ws.numel(), _stream())
     return dfeat, dfeat_out, dw, dbias
+
+
+def pose_length_term(pl_term):
+    """train.py:178-183 from pl_term[B,C,H,W] -> scalar tensor l_pl"""
+    pl_term = pl_term if pl_term.is_contiguous() else pl_term.contiguous()
+    _chk(pl_term)
+    B, C, H, W = pl_term.shape
+    buf = torch.empty((B + 1,), dtype=torch.float32, device=pl_term.device)
+    lib().scat_pose_length_term(_p(pl_term), _p(buf), buf.data_ptr() + 4 * B, B, C, H * W, _stream())
+    return buf[B]
 
 
 def loss_fwd_bwd(out, labels, w3d=100000.0, w2d=10.0):

@@ -39,11 +39,13 @@ def scat_loss(outputs, labels, w3d=100000.0, w2d=10.0):
 
 
 def pose_length_term(pl_term):
-    """train.py:178-183.  A constant w.r.t. the parameters (pl_term has no graph): reported, adds no
-    gradient.  Tiny host-side tensor arithmetic on [B,21,28,28]."""
-    pl_len = pl_term.square().sum(dim=[2, 3]).mean(dim=[1]).sqrt()
-    pl_mean = 0.01 * pl_len.mean()
-    return (pl_len - pl_mean).square().mean()
+    """train.py:178-183.  A constant w.r.t. the parameters (pl_term has no graph): reported, adds no gradient.
+    Two small launches (csrc/misc.hip) instead of a dozen torch reductions."""
+    if not pl_term.is_cuda:
+        pl_len = pl_term.square().sum(dim=[2, 3]).mean(dim=[1]).sqrt()
+        pl_mean = 0.01 * pl_len.mean()
+        return (pl_len - pl_mean).square().mean()
+    return ops.pose_length_term(pl_term)
 
 
 EARLY_ADAM = os.environ.get("SCAT_EARLY_ADAM", "1") != "0"
@@ -146,7 +148,7 @@ class TrainStep:
                 aux.wait_stream(main)
                 with torch.cuda.stream(aux):
                     l_pl = pose_length_term(pl_term)
-                    total = total + 10 * l_pl
+                    total = torch.add(total, l_pl, alpha=10.0)
                 pl_term.record_stream(aux)
                 main.wait_stream(aux)          # (queued behind the whole backward: costs the critical path nothing)
                 l_pl.record_stream(main)

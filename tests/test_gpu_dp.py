@@ -189,3 +189,84 @@ def test_trainstep_two_ranks_one_gpu():
         p.join(60)
     assert all(not isinstance(w, str) for _, w in got), got
     assert sorted(r for r, _ in got) == [0, 1]
+
+
+def _worker_rccl_single(port, out):
+    """ONE rank, backend nccl (= RCCL), SCAT_DP_FORCE_COLLECTIVES=1: everything the N > 1 path does on hardware except
+    talk to a peer — init_process_group(device_id=...), the replica broadcast, the synchronous ReduceOp.AVG probe,
+    all_reduce(async_op=True) per bucket with the private ordering stream current, work.wait() on the optimiser stream
+    (early Adam inside the backward), finish() — with the self-check on.  A one-rank AVG is the identity, so the
+    gradients and the Adam-updated weights must equal a plain single-process twin BIT FOR BIT."""
+    try:
+        import numpy as np
+        import torch.distributed as dist
+
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+                          SCAT_DP_CHECK="1", SCAT_DP_FORCE_COLLECTIVES="1")
+        os.environ.pop("SCAT_DIST_BACKEND", None)
+        from scat_amd import synth
+        from scat_amd.dp import init_distributed
+        from scat_amd.trainer import TrainStep
+        from tests.test_gpu_model import make_encoder
+
+        assert not torch.cuda.is_initialized()       # init_distributed() must come before any GPU call of the process
+        rank, local, world = init_distributed()
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        x, lab = T(synth.images(700, 4)).cuda(), T(synth.labels(710, 4)).cuda()
+        net = make_encoder(43)
+        net.train()
+        ts = TrainStep(net, lr=1e-4)
+        b = ts.buckets
+        assert b.collective and b.world == 1 and b.check
+        probed = b._avg_ok                           # RCCL of ROCm 7 has ReduceOp.AVG; the SUM fallback scales by 1/1
+        issued = []
+        orig = dist.all_reduce
+
+        def spy(t, *a, **k):
+            issued.append((t.numel(), bool(k.get("async_op", False)), torch.cuda.current_stream() == b._comm_stream))
+            return orig(t, *a, **k)
+
+        dist.all_reduce = spy
+        try:
+            random.seed(11)
+            ts(x, lab)
+            random.seed(12)
+            ts(x, lab)                               # a second step: buffers recycled, early Adam waits again
+        finally:
+            dist.all_reduce = orig
+        torch.cuda.synchronize()
+        # 7 buckets per step, all asynchronous, all issued with the ordering stream current
+        assert len(issued) == 2 * len(b.ranges), issued
+        assert all(a and on_c for _, a, on_c in issued), issued
+        assert sorted(n for n, _, _ in issued[:7]) == sorted(e - a for a, e in b.ranges.values())
+        got_g, got_p = b.flat_grad.detach().cpu().clone(), b.flat_param.detach().cpu().clone()
+        # the twin: same process, no collectives at all
+        os.environ["SCAT_DP_FORCE_COLLECTIVES"] = "0"
+        twin = make_encoder(43)
+        twin.train()
+        tts = TrainStep(twin, lr=1e-4)
+        assert not tts.buckets.collective
+        random.seed(11)
+        tts(x, lab)
+        random.seed(12)
+        tts(x, lab)
+        torch.cuda.synchronize()
+        assert torch.equal(got_g, tts.buckets.flat_grad.detach().cpu())
+        assert torch.equal(got_p, tts.buckets.flat_param.detach().cpu())
+        out.put((0, "OK avg=%s" % probed))
+        dist.destroy_process_group()
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        out.put((0, "ERR " + repr(e) + "\n" + traceback.format_exc()))
+
+
+@pytest.mark.timeout(600)
+def test_rccl_single_rank_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl_single, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=500)
+    p.join(60)
+    assert isinstance(got[1], str) and got[1].startswith("OK"), got

@@ -547,7 +547,10 @@ def test_layer4_standalone_on_7x7_maps():
     """``net.layer4(x)`` taken out of the network, train mode, forward + backward (models/resnet.py:78-98, 125-140): its
     block outputs are 7x7 maps, which the 1-bit sign mask cannot pack (H*W % 4 != 0) — the stand-alone block node
     must then keep the output for the ReLU sign of ``relu(bn3(.) + residual)`` instead of deriving it from bn3 alone
-    (ADVICE r02).  Against an fp64 evaluation of the same three Bottlenecks."""
+    (a wrong sign mask is an O(1) error).  Against the oracle's three Bottlenecks in fp64, with the
+    oracle in fp32 as the yardstick: nine batch-statistics BatchNorms over 392 samples and the ReLUs between them make
+    these gradients ill conditioned (the CPU fp32 evaluation itself is ~1 % from fp64), so the HIP gradients must be as
+    close to fp64 as the CPU fp32 ones are (3x + 2e-4), the forward within 2e-5."""
     from scat_amd.models import resnet as R
 
     net = R.resnet50(pretrained=False, num_classes=512)
@@ -557,39 +560,46 @@ def test_layer4_standalone_on_7x7_maps():
     B = 8
     x = T(synth.normal_like(43, "x3", (B, 1024, 14, 14))).abs_()       # (a block input is a ReLU output)
     cot = T(synth.normal_like(44, "cot4", (B, 2048, 7, 7)))
-    sd = {k[len("layer4."):]: v.double() if v.is_floating_point() else v.clone() for k, v in full.items()
-          if k.startswith("layer4.")}
-    for k, v in sd.items():
-        if v.is_floating_point() and "running" not in k:
-            v.requires_grad_(True)
-    xr = x.double().requires_grad_(True)
-    yr = xr
-    for bi in range(3):
-        yr = O.bottleneck(sd, str(bi), yr, 2 if bi == 0 else 1, True)
-    (yr * cot.double()).sum().backward()
+
+    def oracle(dt, blocks, xin, prefix):
+        sd = {k[len(prefix):]: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in full.items()
+              if k.startswith(prefix)}
+        for k, v in sd.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+        xr = xin.to(dt).requires_grad_(True)
+        yr = xr
+        for key, stride in blocks:
+            yr = O.bottleneck(sd, key, yr, stride, True)
+        (yr * cot.to(dt)).sum().backward()
+        return yr.detach(), xr.grad, {k: v.grad for k, v in sd.items() if v.is_floating_point() and v.grad is not None}
+
+    def held(got_x, got_p, r32, r64, what):
+        e_h, e_c = rel_err(got_x, r64[1]), rel_err(r32[1], r64[1])
+        assert e_h <= 3 * e_c + 2e-4, (what, "dx", e_h, e_c)
+        eh = np.array([rel_err(got_p[k], r64[2][k]) for k in r64[2]])
+        ec = np.array([rel_err(r32[2][k], r64[2][k]) for k in r64[2]])
+        assert np.median(eh) <= 2 * np.median(ec) + 2e-4 and eh.max() <= 3 * ec.max() + 2e-4, (what, eh.max(), ec.max())
+
+    blocks = (("0", 2), ("1", 1), ("2", 1))
+    r32, r64 = oracle(torch.float32, blocks, x, "layer4."), oracle(torch.float64, blocks, x, "layer4.")
     xg = x.cuda().requires_grad_(True)
     y = layer4(xg)
     assert tuple(y.shape) == (B, 2048, 7, 7)
-    assert rel_err(y, yr.detach()) < 2e-5
+    assert rel_err(y, r64[0]) < 2e-5
     (y * cot.cuda()).sum().backward()
-    assert rel_err(xg.grad, xr.grad) < 2e-3
-    for k, p in layer4.named_parameters():
-        assert rel_err(p.grad, sd[k].grad) < 2e-3, k
-    # one block alone, no shortcut convolution (the residual is the input itself)
+    held(xg.grad, {k: p.grad for k, p in layer4.named_parameters()}, r32, r64, "layer4")
+    # one block alone, no shortcut convolution (the residual is the block input itself)
     blk = layer4[2]
-    xb = y.detach().clone().requires_grad_(True)
+    xin = y.detach().cpu()
+    xb = xin.cuda().requires_grad_(True)
     for p in blk.parameters():
         p.grad = None
     yb = blk(xb)
     (yb * cot.cuda()).sum().backward()
-    sd2 = {k[len("layer4.2."):]: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v.clone())
-           for k, v in full.items() if k.startswith("layer4.2.")}
-    xbr = y.detach().cpu().double().requires_grad_(True)
-    ybr = O.bottleneck({"b." + k: v for k, v in sd2.items()}, "b", xbr, 1, True)
-    (ybr * cot.double()).sum().backward()
-    assert rel_err(yb, ybr.detach()) < 2e-5
-    assert rel_err(xb.grad, xbr.grad) < 1e-3
-    assert rel_err(blk.conv1.weight.grad, sd2["conv1.weight"].grad) < 1e-3
+    b32, b64 = oracle(torch.float32, (("2", 1),), xin, "layer4."), oracle(torch.float64, (("2", 1),), xin, "layer4.")
+    assert rel_err(yb, b64[0]) < 2e-5
+    held(xb.grad, {"2." + k: p.grad for k, p in blk.named_parameters()}, b32, b64, "layer4.2")
 
 
 def test_backbone_modules_standalone():

@@ -970,3 +970,84 @@ def test_conv1x1_producer_consumer_forms(pc):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SCAT_PC=str(pc)), capture_output=True, text=True,
                        timeout=600, cwd=root)
     assert "PC OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+# persistent stream-K schedule of the pointwise kernels (csrc/conv1x1.hip conv1x1_sk_kernel): a launch needs >= 256 tiles
+# of 128 pixels.  Shapes: tiles split over three workgroups (few stages per workgroup), workgroups with EMPTY ranges
+# (fewer units than workgroups), ragged rows and pixel columns, 64-row tiles; forward (+ fused transform, + BatchNorm sums
+# in the epilogue), data gradient (+ accumulate), the folded-BatchNorm data gradient.  Held to fp64, to the
+# one-tile-per-workgroup kernel, and to itself bit for bit (the partial sums of a tile are added in a fixed order).
+SK_SHAPES = [(28, 256, 256, 28, 28), (7, 64, 256, 56, 56), (5, 96, 200, 63, 52), (10, 128, 64, 60, 60), (5, 512, 1024, 34, 33)]
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", SK_SHAPES)
+def test_conv1x1_streamk(ops, monkeypatch, B, cin, cout, H, W):
+    assert ops.get_math_mode() == 1
+    monkeypatch.setattr(ops, "STREAMK", True)      # (off by default: see ops.STREAMK)
+    gen = torch.Generator().manual_seed(B * 1000 + cin + cout)
+    x = torch.randn((B, cin, H, W), generator=gen)
+    w = torch.randn((cout, cin, 1, 1), generator=gen) * (2.0 / cin) ** 0.5
+    sc, sh = torch.rand((cin,), generator=gen) + 0.5, torch.rand((cin,), generator=gen) - 0.5
+    a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    xg, wg = g(x), g(w)
+
+    def both(fn):
+        """-> (stream-K result, its label, one-tile-per-workgroup result)"""
+        r1 = fn().clone()
+        lab = ops.lib().scat_last_kernel().decode()
+        r2 = fn().clone()
+        assert torch.equal(r1, r2), "stream-K result is not reproducible"
+        ops.STREAMK = False
+        try:
+            r0 = fn().clone()
+            assert not ops.lib().scat_last_kernel().decode().endswith("_sk")
+        finally:
+            ops.STREAMK = True
+        return r1, lab, r0
+
+    y, lab, y0 = both(lambda: ops.conv2d_fwd(xg, wg, 1, 0, g(sc), g(sh), True))
+    assert lab.endswith("_sk"), lab
+    yr = F.conv2d(a.double(), w.double())
+    assert rel_err(y, yr) < 2e-5 and rel_err(y, y0) < 5e-6
+    # BatchNorm sums from the epilogue of a stream-K launch
+    ys = ops.conv2d_fwd(xg, wg, 1, 0, stats=True)
+    assert ops.lib().scat_last_kernel().decode().endswith("_sk") and getattr(ys, "scat_stats", None) is not None
+    ones, zeros = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+    mean, invstd, _, _ = ops.bn_train_stats(ys, ones, zeros, zeros.clone(), ones.clone())
+    yp = F.conv2d(x.double(), w.double())
+    assert rel_err(ys, yp) < 2e-5
+    assert rel_err(mean, yp.mean(dim=(0, 2, 3))) < 2e-5
+    assert rel_err(invstd, (yp.var(dim=(0, 2, 3), unbiased=False) + 1e-5).rsqrt()) < 2e-5
+    # data gradient of the transposed role (M = cout rows here: a convolution cout <- cin seen from its output side)
+    dy = torch.randn((B, cin, H, W), generator=gen)
+    wt = torch.randn((cin, cout, 1, 1), generator=gen) * (2.0 / cout) ** 0.5
+    base = torch.randn((B, cout, H, W), generator=gen)
+    dxr = F.conv_transpose2d(dy.double(), wt.double())
+    dx, lab, dx0 = both(lambda: ops.conv2d_dgrad_w(g(dy), g(wt), (B, cout, H, W), 1, 0))
+    assert lab.endswith("_sk"), lab
+    assert rel_err(dx, dxr) < 2e-5 and rel_err(dx, dx0) < 5e-6
+    dxa = ops.conv2d_dgrad_w(g(dy), g(wt), (B, cout, H, W), 1, 0, out=g(base), accumulate=True)
+    assert ops.lib().scat_last_kernel().decode().endswith("_sk")
+    assert rel_err(dxa, dxr + base.double()) < 2e-5
+    # folded BatchNorm backward: operand ca*g + cb*z + cc formed in the load (dual source)
+    if cin % 16 == 0 and (H * W) % 4 == 0:
+        z = torch.randn((B, cin, H, W), generator=gen)
+        coef = torch.rand((3, cin), generator=gen) - 0.5
+        v = lambda i: coef[i].view(1, -1, 1, 1).double()
+        dzr = F.conv_transpose2d(v(0) * dy.double() + v(1) * z.double() + v(2), wt.double())
+        dzb, lab, dzb0 = both(lambda: ops.conv1x1_dgrad_bnb(g(dy), g(z), g(coef), g(wt), (B, cout, H, W)))
+        assert lab.endswith("_sk"), lab
+        assert rel_err(dzb, dzr) < 2e-5 and rel_err(dzb, dzb0) < 5e-6
+    ops.streamk_check()
+
+
+@pytest.mark.parametrize("B,C,H,W", [(96, 21, 28, 28), (3, 5, 7, 9), (1, 21, 28, 28)])
+def test_pose_length_term(ops, B, C, H, W):
+    """train.py:178-183 as two launches (scat_pose_length_term) against the torch expression of the reference"""
+    pl = t(300, "pl", (B, C, H, W), 0.01)
+    lens = torch.sum(torch.square(pl.double()), dim=[2, 3]).mean(dim=[1]).sqrt()
+    ref = torch.square(lens - 0.01 * torch.mean(lens)).mean()
+    got = ops.pose_length_term(g(pl))
+    assert got.shape == () and abs(got.item() - ref.item()) <= 1e-6 * abs(ref.item())
+    got_view = ops.pose_length_term(g(pl).transpose(2, 3).contiguous().transpose(2, 3))    # non-contiguous input
+    assert abs(got_view.item() - ref.item()) <= 1e-6 * abs(ref.item())

@@ -31,3 +31,11 @@ for cin, cout, H in ((512, 256, 28), (256, 1024, 14), (64, 256, 56), (2048, 512,
         print(f"   {name:10s} us: min {dlt.min():6.1f} median {np.median(dlt):6.1f} max {dlt.max():6.1f}")
     st = np.sort(t[:, 0] - base)
     print("   tile starts (us) percentiles 0/25/50/75/100:", np.round(np.percentile(st, [0, 25, 50, 75, 100]), 1))
+    # first round (tiles that start within 5 us of the kernel's first tile) against the rest
+    first = (t[:, 0] - base) < 5.0
+    for name, sel in (("first round", first), ("later tiles", ~first)):
+        if sel.sum():
+            tt = t[sel]
+            print(f"   {name:11s}: {sel.sum():5d} stamped tiles; start {np.median(tt[:, 0] - base):6.1f}; prologue "
+                  f"{np.median(tt[:, 1] - tt[:, 0]):5.1f} loop {np.median(tt[:, 2] - tt[:, 1]):5.1f} epilogue "
+                  f"{np.median(tt[:, 3] - tt[:, 2]):5.1f}; ends at {np.median(tt[:, 3] - base):6.1f} (max {(tt[:, 3] - base).max():6.1f})")
