@@ -59,6 +59,16 @@ WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW);
 void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, float* out, int B, int Cin, int H, int W,
                         int Cout, int KK, int stride, const float* in_scale, const float* in_shift, int in_relu,
                         hipStream_t st, const float* dy2 = nullptr, const float* coef3 = nullptr);
+// pointwise weight gradient, second generation (conv_wgrad_pw.hip): 32-pixel stages read a cache line per row, 256 x 128
+// tiles on eight consumer + four producer wavefronts.  ok = false: the shape stays on the kernels above.
+struct WgPwPlan {
+    bool ok;
+    int wa, wb, stages, spz, splits;
+};
+WgPwPlan wgrad_pw_plan(int B, int Cin, int Cout, int HW, bool dsa, const void* dy, const void* x);
+void wgrad_pw_launch(const WgPwPlan& p, const float* dy, const float* x, float* out, int B, int Cin, int HW, int Cout,
+                     const float* in_scale, const float* in_shift, int in_relu, hipStream_t st,
+                     const float* dy2 = nullptr, const float* coef3 = nullptr);
 // row-walking 3x3 / stride-1 weight gradient for 32- and 64-channel layers (conv_wgrad_rows.hip)
 bool wgrad_rows_ok(int B, int Cin, int H, int W, int Cout, int KH, int stride, int pad, const void* dy, const void* x);
 int64_t wgrad_rows_ws(int B, int Cin, int H, int W, int Cout);

@@ -170,6 +170,11 @@ extern "C" int64_t scat_conv2d_wgrad_ws(int B, int Cin, int H, int W, int Cout, 
         const int64_t n3 = wgrad_rows_ws(B, Cin, H, W, Cout);
         if (n3 > need) need = n3;
     }
+    if (KH == 1 && stride == 1 && pad == 0) {
+        const WgPwPlan w = wgrad_pw_plan(B, Cin, Cout, OH * OW, false, nullptr, nullptr);
+        const int64_t n4 = w.ok && w.splits > 1 ? (int64_t)w.splits * Cout * Cin * sizeof(float) : 0;
+        if (n4 > need) need = n4;
+    }
     return need;
 }
 
@@ -184,11 +189,25 @@ extern "C" int scat_conv1x1_wgrad_bnb(const float* g, const float* z, const floa
     SCAT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), SCAT_E_ARG, "scat_conv1x1_wgrad_bnb: scale/shift pair");
     SCAT_REQUIRE(fits_i32((int64_t)B * Cout * HW * 4) && fits_i32((int64_t)B * Cin * HW * 4), SCAT_E_SHAPE,
                  "scat_conv1x1_wgrad_bnb: tensor exceeds 32-bit byte offsets");
+    hipStream_t st = (hipStream_t)stream;
+    const WgPwPlan w = wgrad_pw_plan(B, Cin, Cout, HW, true, g, x);
+    if (w.ok && ((uintptr_t)z & 15) == 0) {
+        const int64_t needw = w.splits > 1 ? (int64_t)w.splits * Cout * Cin * sizeof(float) : 0;
+        SCAT_REQUIRE(ws_bytes >= needw && (needw == 0 || ws), SCAT_E_WORKSPACE,
+                     "scat_conv1x1_wgrad_bnb: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)needw);
+        wgrad_pw_launch(w, g, x, w.splits > 1 ? (float*)ws : dw, B, Cin, HW, Cout, in_scale, in_shift,
+                        in_scale ? in_relu : 0, st, z, coef3);
+        SCAT_LAUNCH_CHECK("scat_conv1x1_wgrad_bnb(pw)");
+        if (w.splits > 1) {
+            launch_splitk_reduce((const float*)ws, dw, (int64_t)Cout * Cin, w.splits, 0, st);
+            SCAT_LAUNCH_CHECK("scat_conv1x1_wgrad_bnb(reduce)");
+        }
+        return SCAT_OK;
+    }
     const WgSplitPlan q = wgrad_split_plan(B, Cin, Cout, 1, HW);
     const int64_t need = q.splits > 1 ? (int64_t)q.splits * q.M * q.N * sizeof(float) : 0;
     SCAT_REQUIRE(ws_bytes >= need && (need == 0 || ws), SCAT_E_WORKSPACE,
                  "scat_conv1x1_wgrad_bnb: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
-    hipStream_t st = (hipStream_t)stream;
     wgrad_split_launch(q, g, x, q.splits > 1 ? (float*)ws : dw, B, Cin, 1, HW, Cout, 1, 1, in_scale, in_shift,
                        in_scale ? in_relu : 0, st, z, coef3);
     SCAT_LAUNCH_CHECK("scat_conv1x1_wgrad_bnb");
@@ -201,7 +220,10 @@ extern "C" int scat_conv1x1_wgrad_bnb(const float* g, const float* z, const floa
 }
 extern "C" int64_t scat_conv1x1_wgrad_bnb_ws(int B, int Cin, int HW, int Cout) {
     const WgSplitPlan q = wgrad_split_plan(B, Cin, Cout, 1, HW);
-    return q.splits > 1 ? (int64_t)q.splits * q.M * q.N * sizeof(float) : 0;
+    int64_t need = q.splits > 1 ? (int64_t)q.splits * q.M * q.N * sizeof(float) : 0;
+    const WgPwPlan w = wgrad_pw_plan(B, Cin, Cout, HW, true, nullptr, nullptr);
+    const int64_t needw = w.ok && w.splits > 1 ? (int64_t)w.splits * Cout * Cin * sizeof(float) : 0;
+    return needw > need ? needw : need;
 }
 
 extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout,
@@ -224,6 +246,23 @@ extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int
         launch_splitk_reduce((const float*)ws, dw, (int64_t)Cout * Cin * 9, splits, 0, st3);
         SCAT_LAUNCH_CHECK("scat_conv2d_wgrad(reduce)");
         return SCAT_OK;
+    }
+    if (math_mode() == 1 && KH == 1 && KW == 1 && stride == 1 && pad == 0 &&
+        fits_i32((int64_t)B * Cout * H * W * 4) && fits_i32((int64_t)B * Cin * H * W * 4)) {
+        const WgPwPlan w = wgrad_pw_plan(B, Cin, Cout, H * W, false, dy, x);
+        if (w.ok) {
+            const int64_t need4 = w.splits > 1 ? (int64_t)w.splits * Cout * Cin * sizeof(float) : 0;
+            SCAT_REQUIRE(ws_bytes >= need4 && (need4 == 0 || ws), SCAT_E_WORKSPACE,
+                         "scat_conv2d_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need4);
+            hipStream_t st4 = (hipStream_t)stream;
+            wgrad_pw_launch(w, dy, x, w.splits > 1 ? (float*)ws : dw, B, Cin, H * W, Cout, in_scale, in_shift, in_relu, st4);
+            SCAT_LAUNCH_CHECK("scat_conv2d_wgrad(pw)");
+            if (w.splits > 1) {
+                launch_splitk_reduce((const float*)ws, dw, (int64_t)Cout * Cin, w.splits, 0, st4);
+                SCAT_LAUNCH_CHECK("scat_conv2d_wgrad(reduce)");
+            }
+            return SCAT_OK;
+        }
     }
     if (math_mode() == 1 && wgrad_split_ok(KH, stride, pad, Cout, Cin)) {
         const WgSplitPlan q = wgrad_split_plan(B, Cin, Cout, KH * KW, OH * OW);

@@ -63,6 +63,8 @@ def _upload_indices(idx, device):
 
 
 OVERLAP_TOKENS = os.environ.get("SCAT_OVERLAP_TOKENS", "1") != "0"   # token path next to layer3/layer4 (own stream)
+TOKENS_FIRST_IN_BACKWARD = os.environ.get("SCAT_TOKENS_FIRST", "1") != "0"   # (0: the round-2 node order, for A/B runs)
+TOKEN_PRIO = os.environ.get("SCAT_TOKEN_PRIO", "0") != "0"   # token stream with high priority (A/B switch)
 _TOKEN_STREAMS = {}
 # The token-path parameters get their gradients from nodes that ran on the token stream while their AccumulateGrad
 # nodes belong to the caller's stream: autograd orders the two (that is the design) and says so once per process.
@@ -72,7 +74,7 @@ warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does
 def _token_stream(device):
     key = str(device)
     if key not in _TOKEN_STREAMS:
-        _TOKEN_STREAMS[key] = torch.cuda.Stream(device=device)
+        _TOKEN_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if TOKEN_PRIO else 0)
         from ..dp import register_producer
         register_producer(_TOKEN_STREAMS[key])
     return _TOKEN_STREAMS[key]
@@ -91,11 +93,22 @@ def _backbone_with_tokens(backbone, main_input, token_path):
     main = torch.cuda.current_stream()
     ts = _token_stream(main_input.device)
     x1, x2, x2b = backbone.first_half(main_input)      # (x2b: the same tensor as a second autograd output)
-    ts.wait_stream(main)
-    with torch.cuda.stream(ts):
-        outs = token_path(x2)
-    x2.record_stream(ts)
-    main_feat, x3, x4 = backbone.second_half(x2b)
+    ts.wait_stream(main)                               # (the token stream waits for the first half only)
+    if TOKENS_FIRST_IN_BACKWARD:
+        # Autograd runs ready nodes in the reverse of their creation order, one after the other on the host: created
+        # BEFORE second_half, the token path's ~100 small backward kernels were only enqueued once the host had issued the
+        # whole layer4 / layer3 backward, reached the GPU at its end and kept first_half's backward waiting (it needs their
+        # gradient of x2) — 1-2 ms of an otherwise idle main queue in the kernel trace.  Created AFTER it, they are
+        # enqueued first and run under layer4's backward.  The forward does not care: the host is far ahead there.
+        main_feat, x3, x4 = backbone.second_half(x2b)
+        with torch.cuda.stream(ts):
+            outs = token_path(x2)
+        x2.record_stream(ts)
+    else:
+        with torch.cuda.stream(ts):
+            outs = token_path(x2)
+        x2.record_stream(ts)
+        main_feat, x3, x4 = backbone.second_half(x2b)
     main.wait_stream(ts)
     for t in outs:
         if isinstance(t, torch.Tensor):

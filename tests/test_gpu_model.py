@@ -562,12 +562,12 @@ def test_layer4_standalone_on_7x7_maps():
     cot = T(synth.normal_like(44, "cot4", (B, 2048, 7, 7)))
 
     def oracle(dt, blocks, xin, prefix):
-        sd = {k[len(prefix):]: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in full.items()
-              if k.startswith(prefix)}
+        sd = {k[len(prefix):]: (v.detach().clone().to(dt) if v.is_floating_point() else v.clone())
+              for k, v in full.items() if k.startswith(prefix)}
         for k, v in sd.items():
             if v.is_floating_point() and "running" not in k:
                 v.requires_grad_(True)
-        xr = xin.to(dt).requires_grad_(True)
+        xr = xin.detach().clone().to(dt).requires_grad_(True)
         yr = xr
         for key, stride in blocks:
             yr = O.bottleneck(sd, key, yr, stride, True)

@@ -1051,3 +1051,43 @@ def test_pose_length_term(ops, B, C, H, W):
     assert got.shape == () and abs(got.item() - ref.item()) <= 1e-6 * abs(ref.item())
     got_view = ops.pose_length_term(g(pl).transpose(2, 3).contiguous().transpose(2, 3))    # non-contiguous input
     assert abs(got_view.item() - ref.item()) <= 1e-6 * abs(ref.item())
+
+
+# second-generation pointwise weight gradient (csrc/conv_wgrad_pw.hip): every tile shape (256x128, 128x256, 128x128,
+# 256x64, 64x256), partial tiles (channel counts that are multiples of 64 but not of the tile), planes whose size is not
+# a multiple of 8 (last octet of an image half empty) or of 4 (7x7: pixel-by-pixel loads), split-K slices that end
+# inside an image, the fused input transform on x, the folded BatchNorm backward on dy.
+WGPW = [
+    # B, Cin, Cout, H, W, tf
+    (5, 128, 512, 14, 14, True), (3, 512, 128, 12, 10, False), (4, 256, 256, 7, 7, True), (6, 192, 320, 14, 14, False),
+    (2, 64, 256, 28, 28, True), (3, 256, 64, 20, 22, False), (7, 1024, 256, 7, 7, False), (2, 128, 128, 14, 18, True),
+    (3, 320, 192, 5, 5, True), (9, 2048, 512, 7, 7, False),
+]
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,tf", WGPW)
+def test_wgrad1x1_pw(ops, B, cin, cout, H, W, tf):
+    assert ops.get_math_mode() == 1
+    gen = torch.Generator().manual_seed(B * 131 + cin + 3 * cout)
+    x = torch.randn((B, cin, H, W), generator=gen)
+    dy = torch.randn((B, cout, H, W), generator=gen)
+    sc, sh = torch.rand((cin,), generator=gen) + 0.5, torch.rand((cin,), generator=gen) - 0.5
+    a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if tf else x
+    ref = torch.einsum("nop,nip->oi", dy.double().flatten(2), a.double().flatten(2)).view(cout, cin, 1, 1)
+    tfa = (g(sc), g(sh), True) if tf else (None, None, False)
+    dw = ops.conv2d_wgrad(g(dy), g(x), (cout, cin, 1, 1), 1, 0, *tfa)
+    lab = ops.lib().scat_last_kernel().decode()
+    assert lab.startswith("wgrad1x1_pw_"), lab
+    assert ("_rag" in lab) == ((H * W) % 4 != 0)
+    assert rel_err(dw, ref) < 2e-5
+    assert torch.equal(dw, ops.conv2d_wgrad(g(dy), g(x), (cout, cin, 1, 1), 1, 0, *tfa))      # deterministic split-K
+    if (H * W) % 4 == 0:       # folded BatchNorm backward: dy = ca*g + cb*z + cc formed in the load
+        z = torch.randn((B, cout, H, W), generator=gen)
+        coef = torch.rand((3, cout), generator=gen) - 0.5
+        v = lambda i: coef[i].view(1, -1, 1, 1).double()
+        dz = v(0) * dy.double() + v(1) * z.double() + v(2)
+        refb = torch.einsum("nop,nip->oi", dz.flatten(2), a.double().flatten(2)).view(cout, cin, 1, 1)
+        dwb = ops.conv1x1_wgrad_bnb(g(dy), g(z), g(coef), g(x), (cout, cin, 1, 1), *tfa)
+        lab = ops.lib().scat_last_kernel().decode()
+        assert lab.startswith("wgrad1x1_pw_") and "_bnb" in lab, lab
+        assert rel_err(dwb, refb) < 2e-5
