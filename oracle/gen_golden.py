@@ -214,13 +214,16 @@ def g_h3dw():
     feat, pred = net(x)
     out["eval:feat"] = feat.detach().numpy()
     out["eval:pred"] = pred.detach().numpy()
+    # head gradients on a frozen, eval-mode backbone (batch-1 train-mode BatchNorm statistics of a 7x7 map are noise;
+    # fine-tuning the regressor on fixed features is the one way this class is trained at batch 1)
     net.train()
-    net.main_encoder.eval()       # batch-1 train-mode BatchNorm statistics of a 7x7 map are noise; keep them fixed
+    net.main_encoder.eval()
+    for p in net.main_encoder.parameters():
+        p.requires_grad_(False)
     feat, pred = net(x)
     (pred * T(synth.normal_like(84, "cot", (1, 61)))).sum().backward()
     out["train:pred"] = pred.detach().numpy()
-    for k in ("feat_encoder.1.weight", "regressor.0.weight", "regressor.0.bias", "main_encoder.fc1.weight",
-              "main_encoder.layer4.2.conv3.weight"):
+    for k in ("feat_encoder.1.weight", "feat_encoder.1.bias", "regressor.0.weight", "regressor.0.bias"):
         out["g:" + k] = digest(dict(net.named_parameters())[k].grad, 16)
     np.savez(os.path.join(GOLD, "h3dw.npz"), **out)
 

@@ -797,13 +797,14 @@ def test_h3dw_encoder_golden(golden):
         feat, pred = net(x)
     assert rel_err(feat, g["eval:feat"]) < 1e-4 and rel_err(pred, g["eval:pred"]) < 1e-4
     net.train()
-    net.main_encoder.eval()
+    net.main_encoder.eval()                      # head gradients on a frozen, eval-mode backbone (see gen_golden.g_h3dw)
+    for p in net.main_encoder.parameters():
+        p.requires_grad_(False)
     feat, pred = net(x)
     assert rel_err(pred, g["train:pred"]) < 1e-4
     (pred * T(synth.normal_like(84, "cot", (1, 61))).cuda()).sum().backward()
     named = dict(net.named_parameters())
-    for k in ("feat_encoder.1.weight", "regressor.0.weight", "regressor.0.bias", "main_encoder.fc1.weight",
-              "main_encoder.layer4.2.conv3.weight"):
+    for k in ("feat_encoder.1.weight", "feat_encoder.1.bias", "regressor.0.weight", "regressor.0.bias"):
         assert digest_err(digest(named[k].grad, 16), g["g:" + k]) < 5e-4, k
     with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
         net(torch.cat((x, x)))
