@@ -318,6 +318,13 @@ def main():
                     "host memory (double-buffered H2D; reported as config.pcie_inclusive, never as value)")
     a = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when its first communicator
+    # comes up (seen with a one-rank nccl group, profiles/r03_rccl_single_rank.txt): keep the real stdout for the line
+    # and point file descriptor 1 at stderr for everything else, native libraries included.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     # distributed first: RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run, the device is chosen and the
     # process group created before anything touches the GPU
     from scat_amd.dp import init_distributed
@@ -405,7 +412,7 @@ def main():
                        "whole_step_tflops_per_gpu": round(step_tf, 2), "pcie_inclusive": pcie},
             "roofline": roof, "roofline_hbm": roof_hbm, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
         if a.kernel_table:
             print(json.dumps(table, indent=1), file=sys.stderr)
     if world > 1:
