@@ -68,7 +68,7 @@ def main():
         finally:
             for fn, f in saved.items():
                 setattr(L, fn, f)
-        print(f"without {name:12s} {ms:7.2f} ms   ({base - ms:+.2f} ms on the step)", flush=True)
+        print(f"without {name:12s} {ms:7.2f} ms   (the class costs the step {base - ms:.2f} ms)", flush=True)
 
 
 if __name__ == "__main__":
