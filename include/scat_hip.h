@@ -153,6 +153,22 @@ int64_t scat_gemm_ws(int M, int N, int K);
 int scat_gemm(const float* a, int64_t a_si, int64_t a_sk, const float* b, int64_t b_sk, int64_t b_sj, float* c,
               int64_t c_si, int64_t c_sj, int M, int N, int K, const float* bias, int bias_mode, int accumulate,
               void* ws, int64_t ws_bytes, void* stream);
+/* n <= 16 independent contractions c_q[M_q,N_q] = A_q . B_q in ONE launch (+ one fixed-order split-K reduce): the twelve
+ * weight gradients of the token mixer's backward (to_qkv / to_out / FeedForward of the three layers,
+ * models/vision_transformer.py:33-35,52-57 through autograd), each too small to fill the chip on its own.  Operand
+ * layout of a weight gradient only: A and B contiguous along their output index (a_si == 1, b_sj == 1), the same
+ * contraction length K for every problem.  `problems` is a HOST array; ws: scat_gemm_group_ws() bytes, 16-B aligned. */
+typedef struct ScatGemmProblem {
+    const float* a;
+    int64_t a_si, a_sk;
+    const float* b;
+    int64_t b_sk, b_sj;
+    float* c;
+    int64_t c_si, c_sj;
+    int M, N, K;
+} ScatGemmProblem;
+int64_t scat_gemm_group_ws(const ScatGemmProblem* problems, int n);
+int scat_gemm_group(const ScatGemmProblem* problems, int n, void* ws, int64_t ws_bytes, void* stream);
 
 /* The same contraction on split-operand products (scat_get_math_mode() == 1), for the dense projections of the ViT
  * blocks (models/vision_transformer.py:52,57,76: to_qkv, to_out and their gradients; FeedForward :33-35):

@@ -519,9 +519,11 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[MI][NI], const OutDesc&
 // PD = prefetch distance in K-steps.  PD = 1: the loads of step t+1 fly under the MFMAs of step t.
 // PD = 2: a second register set keeps the loads of step t+2 in flight as well (twice the bytes in flight per
 // CU — what the HBM-bound short-K layers need, MI355X wants >= 64 KiB in flight per CU to hide an HBM miss).
+// one (tile, K-slice) of a contraction: the body of gemm_kernel, and of the grouped launch in linear.hip
 template <class LA, class LB, int BM, int BN, int BK, int WM, int WN, int PD = 1>
-__global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename LB::Desc db, OutDesc dc,
-                                                  int M, int N, int K, int kchunk) {
+__device__ __forceinline__ void gemm_tile(const typename LA::Desc& da, const typename LB::Desc& db, const OutDesc& dc,
+                                          const int M, const int N, const int K, const int kchunk, const int tile,
+                                          const int z) {
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     static_assert(WM * WN == 4 && MI >= 1 && NI >= 1, "wave layout");
     static_assert(PD == 1 || PD == 2, "prefetch distance");
@@ -530,10 +532,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename
     auto As = [&](int buf) -> float* { return lds + buf * (BK * SA); };
     auto Bs = [&](int buf) -> float* { return lds + 2 * BK * SA + buf * (BK * SB); };
 
-    const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int mt = (M + BM - 1) / BM;
     const int i0 = (tile % mt) * BM, j0 = (tile / mt) * BN;   // m fastest: neighbours share the B panel
-    const int z = blockIdx.z;
     const int kbeg = z * kchunk, kend = min(K, kbeg + kchunk);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -636,6 +636,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename
     }
 
     store_tile<MI, NI, BM, BN, WM, WN>(acc, dc, M, N, i0, j0, z);
+}
+
+template <class LA, class LB, int BM, int BN, int BK, int WM, int WN, int PD = 1>
+__global__ __launch_bounds__(NT) void gemm_kernel(typename LA::Desc da, typename LB::Desc db, OutDesc dc,
+                                                  int M, int N, int K, int kchunk) {
+    const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
+    gemm_tile<LA, LB, BM, BN, BK, WM, WN, PD>(da, db, dc, M, N, K, kchunk, xcd_remap(blockIdx.x, mt * nt), blockIdx.z);
 }
 
 // deterministic split-K combine: out[e] (+)= sum_z slab[z][e], fixed order

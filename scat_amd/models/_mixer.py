@@ -122,6 +122,16 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
         side = _rn._side_stream(d.device, "tokens")
         main = torch.cuda.current_stream()
 
+    # the weight-gradient contractions (four per layer, independent of everything in this backward) are collected and
+    # issued as ONE grouped launch at the end instead of twelve small ones next to the data-gradient chain
+    group = [] if (want_param_grads and d.is_cuda and ops.GROUP_WGRAD) else None
+
+    def wgrad(slot, dy2d, x2d):
+        if group is None:
+            grads[slot] = pgrad(lambda: ops.linear_wgrad(dy2d, x2d), dy2d, x2d)
+        else:
+            group.append((slot, dy2d, x2d))
+
     def pgrad(fn, *inputs):
         if side is None:
             return fn()
@@ -130,7 +140,8 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
             out = fn()
         for t in inputs:
             t.record_stream(side)
-        out.record_stream(main)
+        for o in (out if isinstance(out, (list, tuple)) else (out,)):
+            o.record_stream(main)
         return out
 
     for cfg, rec in zip(reversed(tape.cfgs), reversed(tape.recs)):
@@ -148,11 +159,11 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
         # ---- MLP
         da = ops.linear_dgrad(d, w2)
         if want_param_grads:
-            grads[pi + kf + 2] = pgrad(lambda d=d, a=a: ops.linear_wgrad(d, a), d, a)
+            wgrad(pi + kf + 2, d, a)
             grads[pi + kf + 3] = pgrad(lambda d=d: ops.colsum(d), d)
         du = ops.gelu_bwd(da, u)
         if want_param_grads:
-            grads[pi + kf] = pgrad(lambda du=du, h2=h2: ops.linear_wgrad(du, h2), du, h2)
+            wgrad(pi + kf, du, h2)
             grads[pi + kf + 1] = pgrad(lambda du=du: ops.colsum(du), du)
         dh2 = ops.linear_dgrad(du, w0)
         if cfg.ff_ln:
@@ -171,13 +182,13 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
         else:
             da1 = dx1
         if want_param_grads:
-            grads[pi + k + 1] = pgrad(lambda da1=da1, ao=ao: ops.linear_wgrad(da1, ao.view(M, inner)), da1, ao)
+            wgrad(pi + k + 1, da1, ao.view(M, inner))
             grads[pi + k + 2] = pgrad(lambda da1=da1: ops.colsum(da1), da1)
         dao = ops.linear_dgrad(da1, wout)
         dqkv = ops.attention_bwd(dao.view(B, n, inner), qkv.view(B, n, 3 * inner), attn, cfg.heads, cfg.dim_head,
                                  cfg.scale).view(M, 3 * inner)
         if want_param_grads:
-            grads[pi + k] = pgrad(lambda dqkv=dqkv, h=h: ops.linear_wgrad(dqkv, h), dqkv, h)
+            wgrad(pi + k, dqkv, h)
         dh = ops.linear_dgrad(dqkv, wqkv)
         if cfg.ln1:
             dx, dg1, db1 = ops.layernorm_bwd(dh, cur, p[0], mu1, rs1)
@@ -186,6 +197,11 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
         else:
             dx = dh
         d = ops.axpy(dx, dx1, 1.0, out=dx)
+    if group:
+        pairs = [(dy2d, x2d) for _, dy2d, x2d in group]
+        outs = pgrad(lambda: ops.linear_wgrad_group(pairs), *[t for pr in pairs for t in pr])
+        for (slot, _, _), g in zip(group, outs):
+            grads[slot] = g
     if side is not None:
         main.wait_stream(side)
     return d.view(B, n, -1), (grads if want_param_grads else None)

@@ -462,6 +462,40 @@ def linear_wgrad(dy2d, x2d, out=None):
     return gemm(dy2d, 1, N, x2d, K, 1, dw, K, 1, N, K, M)
 
 
+class _GemmProblem(ctypes.Structure):
+    """include/scat_hip.h ScatGemmProblem"""
+    _fields_ = [("a", ctypes.c_void_p), ("a_si", ctypes.c_int64), ("a_sk", ctypes.c_int64),
+                ("b", ctypes.c_void_p), ("b_sk", ctypes.c_int64), ("b_sj", ctypes.c_int64),
+                ("c", ctypes.c_void_p), ("c_si", ctypes.c_int64), ("c_sj", ctypes.c_int64),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int)]
+
+
+GROUP_WGRAD = os.environ.get("SCAT_GROUP_WGRAD", "1") != "0"   # the token mixer's weight gradients as one launch
+GROUP_MAX = 16
+
+
+def linear_wgrad_group(pairs):
+    """[(dy2d[M,N_q], x2d[M,K_q]), ...] -> [dw_q[N_q,K_q] = dy_q^T @ x_q] with ONE launch (scat_gemm_group): the
+    independent weight gradients of a token mixer's backward (same token count M for all), <= 16 per call."""
+    outs = []
+    for i0 in range(0, len(pairs), GROUP_MAX):
+        chunk = pairs[i0:i0 + GROUP_MAX]
+        arr = (_GemmProblem * len(chunk))()
+        flops = 0.0
+        for q, (dy, x) in enumerate(chunk):
+            _chk(dy, x)
+            M, N = dy.shape
+            K = x.shape[1]
+            dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+            outs.append(dw)
+            arr[q] = _GemmProblem(_p(dy), 1, N, _p(x), K, 1, _p(dw), K, 1, N, K, M)
+            flops += 2.0 * M * N * K
+        need = lib().scat_gemm_group_ws(arr, len(chunk))
+        ws = workspace(need, chunk[0][0].device, "gg") if need else None
+        _prof(flops, lib().scat_gemm_group, arr, len(chunk), _p(ws), ws.numel() if ws is not None else 0, _stream())
+    return outs
+
+
 def colsum(x2d, out=None, accumulate=False):
     _chk(x2d, out)
     rows, cols = x2d.shape

@@ -1091,3 +1091,21 @@ def test_wgrad1x1_pw(ops, B, cin, cout, H, W, tf):
         lab = ops.lib().scat_last_kernel().decode()
         assert lab.startswith("wgrad1x1_pw_") and "_bnb" in lab, lab
         assert rel_err(dwb, refb) < 2e-5
+
+
+def test_gemm_group(ops):
+    """scat_gemm_group: independent weight-gradient contractions in one launch == the same contractions one by one and
+    fp64 (shapes of the token mixer at batch 96 and ragged ones; split-K inside the group)."""
+    for M, dims in ((2016, [(1536, 784), (784, 512), (588, 784), (392, 588), (1536, 392), (3, 147), (147, 196)]),
+                    (300, [(70, 33), (129, 64), (64, 200)])):
+        gen = torch.Generator().manual_seed(M)
+        pairs, refs = [], []
+        for N, K in dims:
+            dy, x = torch.randn((M, N), generator=gen), torch.randn((M, K), generator=gen)
+            pairs.append((g(dy), g(x)))
+            refs.append(dy.double().t() @ x.double())
+        outs = ops.linear_wgrad_group(pairs)
+        assert ops.lib().scat_last_kernel().decode().startswith("gemm_group")
+        for (dy, x), o, r in zip(pairs, outs, refs):
+            assert rel_err(o, r) < 2e-5
+            assert rel_err(o, ops.linear_wgrad(dy, x)) < 5e-6
