@@ -278,7 +278,9 @@ def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, b
         y = _conv2d_fwd(x, w, stride, pad, in_scale, in_shift, in_relu, bias, out, wp)
     finally:
         groups = lib().scat_epilogue_stats_groups()
-    # the partials live in a recycled workspace: they are only good until the next armed convolution on this stream
+    # the partials live in a recycled workspace: they are only good until the next armed convolution on this stream.
+    # Protocol (same host thread): arm -> convolution -> groups() -> [bn_train_stats takes them]; any other armed
+    # convolution in between bumps the generation and bn_train_stats falls back to the pass over y.
     _EPI_GEN[0] += 1
     y.scat_stats = (part, groups, _EPI_GEN[0]) if groups > 0 else None
     return y
@@ -384,8 +386,11 @@ def conv2d_wgrad(dy, x, w_shape, stride, pad, in_scale=None, in_shift=None, in_r
     Cout, _, KH, KW = w_shape
     dw = out if out is not None else torch.empty(w_shape, dtype=torch.float32, device=x.device)
     OH, OW = conv_out_hw(H, W, KH, stride, pad)
+    # (the C entry also wants dy 16-byte aligned and 2*OW + 5 input columns in its LDS row: mirrored here so that
+    # anything else falls through to the general engine instead of raising — ADVICE r02)
     if (KH == 7 and KW == 7 and stride == 2 and pad == 3 and Cin == 3 and Cout == 64 and in_scale is None
-            and OW % 16 == 0 and OW <= 112 and lib().scat_get_math_mode() == 1 and STEM_SPLIT):
+            and OW % 16 == 0 and OW <= 112 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+            and lib().scat_get_math_mode() == 1 and STEM_SPLIT):
         ws = workspace(lib().scat_conv7x7_s2_wgrad_split_ws(B, H, W), x.device, ws_slot)
         _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv7x7_s2_wgrad_split, _p(dy), _p(x), _p(dw), B, H, W,
               Cout, _p(ws), ws.numel(), _stream())
