@@ -59,6 +59,41 @@ WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW);
 void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, float* out, int B, int Cin, int H, int W,
                         int Cout, int KK, int stride, const float* in_scale, const float* in_shift, int in_relu,
                         hipStream_t st, const float* dy2 = nullptr, const float* coef3 = nullptr);
+// XCD-local split-K: the tiles of one split-K slice of a weight gradient read the same pixels of both operands, so they
+// should run on ONE XCD (one L2) at about the same time.  Hardware deals block b to XCD b % 8 (MI355X_MICROARCH.md,
+// workgroup dispatch).  A slice's `tiles` tiles are cut into `ngroup` contiguous runs of tg = ceil(tiles / ngroup); the
+// unit dealt to an XCD is a (slice, run) pair, numbered v = slice * ngroup + run: block b -> XCD x = b % 8, k = b / 8,
+// position in the run k % tg, v = (k / tg) * 8 + x.  ngroup = 1 (whole slices, grid padded to a multiple of 8 slices)
+// whenever there are many slices; 8 / gcd(8, splits) for the few-slice launches so that all eight XCDs get work.
+static inline int splitk_xcd_groups(int splits) {
+    static const int on = [] { const char* e = getenv("SCAT_WG_XCD"); return e ? atoi(e) : 1; }();
+    if (!on) return 0;         // A/B switch: 0 = tiles in XCD chunks, slices in launch order (the round-2 mapping)
+    if (splits >= 32 || splits % 8 == 0) return 1;
+    int g = 8;
+    while (g > 1 && (splits % g)) g >>= 1;      // gcd(8, splits)
+    return 8 / g;
+}
+static inline int splitk_xcd_grid(int tiles, int splits, int ngroup) {
+    if (ngroup == 0) return tiles * splits;
+    const int tg = (tiles + ngroup - 1) / ngroup;
+    const int nv = (splits * ngroup + 7) / 8 * 8;
+    return tg * nv;
+}
+__device__ __forceinline__ bool splitk_xcd_map(int b, int tiles, int splits, int ngroup, int& tile, int& z) {
+    if (ngroup == 0) {
+        z = b / tiles;
+        const int id = b - z * tiles, q = tiles >> 3, r = tiles & 7, x = id & 7, s = id >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;      // xcd_remap of gemm_engine.h
+        return true;
+    }
+    const int tg = (tiles + ngroup - 1) / ngroup;
+    const int k = b >> 3;
+    const int v = (k / tg) * 8 + (b & 7);
+    z = v / ngroup;
+    tile = (v - z * ngroup) * tg + k % tg;
+    return z < splits && tile < tiles;
+}
+
 // pointwise weight gradient, second generation (conv_wgrad_pw.hip): 32-pixel stages read a cache line per row, 256 x 128
 // tiles on eight consumer + four producer wavefronts.  ok = false: the shape stays on the kernels above.
 struct WgPwPlan {

@@ -34,6 +34,7 @@ struct WgPwDesc {
     int NO, U;            // octets per image, octets in total
     int NS;               // stages (4 octets each) in total
     int spz;              // stages per split-K slice
+    int nsplit, ngroup;   // split-K slices; runs a slice's tiles are cut into (splitk_xcd_map)
     FastDiv dNO;
     int64_t ndy, nx;
 };
@@ -42,19 +43,30 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 // WA x WB consumer wavefronts, 64 x 64 outputs each; 4 producer wavefronts.  RAG: HW % 4 != 0 (7 x 7 planes): a quad of
 // pixels may straddle the end of an image, loads go pixel by pixel.
-template <int WA, int WB, bool TF, bool DSA, bool RAG>
-__global__ __launch_bounds__(64 * (WA * WB + 4)) void wgrad_pw_kernel(WgPwDesc d, OutDesc dc) {
+// DIAG (diag build only, results are wrong): 1 = no global loads, 2 = no split arithmetic, 4 = no MFMAs, 8 = no LDS
+// fragment reads, 16 = no LDS writes
+// NP producer wavefronts (4 or 8): a producer's stream is latency-bound when it is alone on its SIMD (the kernel with the
+// MFMAs removed takes as long as with them), two per SIMD hide each other's waits.
+template <int WA, int WB, bool TF, bool DSA, bool RAG, int DIAG = 0, int NP = 4>
+__global__ __launch_bounds__(64 * (WA * WB + NP)) void wgrad_pw_kernel(WgPwDesc d, OutDesc dc) {
     constexpr int NC = WA * WB, RA = 64 * WA, RB = 64 * WB;
     constexpr int OSA = RA + 8, OSB = RB + 8;          // u32x4 per (plane, octet) slab; +128 B: octet o lands 32 banks on
     constexpr int BUF = 12 * (OSA + OSB);              // u32x4 per stage buffer: [A: 3 planes x 4 octets | B: same]
-    constexpr int IA = RA / 32, IB = RB / 32;          // staging items (row, 4 pixels) per producer thread and stage
+    constexpr int PR = 8 * NP;                         // rows covered by the producers per item (8 lanes per row)
+    constexpr int IA = RA / PR, IB = RB / PR;          // staging items (row, 4 pixels) per producer thread and stage
     extern __shared__ __align__(16) float lds[];
     u32x4* const L0 = (u32x4*)lds;
 
+    // The tiles of one split-K slice read the SAME pixels of dy and x (each tile its own rows): they must share an L2.
+    // Hardware deals block b to XCD b % 8, so slice z = 8 * (k / tiles) + b % 8 and tile = k % tiles with k = b / 8: the
+    // tiles of a slice are consecutive blocks of one XCD and every operand panel comes from HBM once, not once per tile
+    // (512->256 @28, four tiles: 462 -> 231 MB per launch).  The grid is padded to a multiple of 8 slices.
+    // With few slices (not a multiple of 8) the tiles of a slice are cut into `ngroup` runs and a (slice, run) pair is
+    // the unit dealt to an XCD, so that all eight XCDs have work (splitk_xcd_map, conv_common.h).
     const int mt = (d.Cout + RA - 1) / RA, nt = (d.Cin + RB - 1) / RB;
-    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    int tile, z;
+    if (!splitk_xcd_map(blockIdx.x, mt * nt, d.nsplit, d.ngroup, tile, z)) return;   // (the whole workgroup: before any barrier)
     const int i0 = (tile % mt) * RA, j0 = (tile / mt) * RB;
-    const int z = blockIdx.z;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int sbeg = z * d.spz, send = min(sbeg + d.spz, d.NS);
@@ -64,7 +76,7 @@ __global__ __launch_bounds__(64 * (WA * WB + 4)) void wgrad_pw_kernel(WgPwDesc d
 
     if (wave >= NC) {
         // ------------------------------------------------------------ producers
-        const int p = threadIdx.x - 64 * NC;           // 0 .. 255
+        const int p = threadIdx.x - 64 * NC;           // 0 .. 64 NP - 1
         const int q = p & 7, rb = p >> 3;              // pixel quad of the stage, first row
         const int oct = q >> 1, half = q & 1;
         const __amdgpu_buffer_rsrc_t rsa = make_rsrc(d.dy, d.ndy), rsb = make_rsrc(d.x, d.nx);
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(64 * (WA * WB + 4)) void wgrad_pw_kernel(WgPwDesc d
         float bsc[TF ? IB : 1], bsh[TF ? IB : 1];
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
-            const int row = i0 + rb + 32 * i;
+            const int row = i0 + rb + PR * i;
             arow_off[i] = row < d.Cout ? row * d.HW * 4 : OOB;
             if constexpr (DSA) {
                 const int r = row < d.Cout ? row : 0;
@@ -83,7 +95,7 @@ __global__ __launch_bounds__(64 * (WA * WB + 4)) void wgrad_pw_kernel(WgPwDesc d
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
-            const int row = j0 + rb + 32 * i;
+            const int row = j0 + rb + PR * i;
             brow_off[i] = row < d.Cin ? row * d.HW * 4 : OOB;
             if constexpr (TF) {
                 const int r = row < d.Cin ? row : 0;
@@ -105,7 +117,9 @@ __global__ __launch_bounds__(64 * (WA * WB + 4)) void wgrad_pw_kernel(WgPwDesc d
             cnt[Q] = c;
             const int pix = r0 * 4;
             auto quad = [&](__amdgpu_buffer_rsrc_t rs, int row_off, int img, float (&v)[4]) {
-                if constexpr (!RAG) {
+                if constexpr (DIAG & 1) {
+                    v[0] = __int_as_float(row_off + c); v[1] = 1.f; v[2] = __int_as_float(pix); v[3] = 2.f;
+                } else if constexpr (!RAG) {
                     const int off = (c > 0 && row_off != OOB) ? (int)n * img + row_off + pix : OOB;
                     const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
                     v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y);
@@ -148,12 +162,21 @@ __global__ __launch_bounds__(64 * (WA * WB + 4)) void wgrad_pw_kernel(WgPwDesc d
                         if (arow_off[i] == OOB) { v[0] = v[1] = v[2] = v[3] = 0.f; }
                     }
                     uint32_t h0, m0, l0, h1, m1, l1;
-                    split3(v[0], v[1], h0, m0, l0);
-                    split3(v[2], v[3], h1, m1, l1);
-                    u32x2_t* o = A2 + (rb + 32 * i) * 2;
+                    if constexpr (DIAG & 2) {
+                        h0 = __float_as_uint(v[0]); m0 = __float_as_uint(v[1]); l0 = h0 ^ m0;
+                        h1 = __float_as_uint(v[2]); m1 = __float_as_uint(v[3]); l1 = h1 ^ m1;
+                    } else {
+                        split3(v[0], v[1], h0, m0, l0);
+                        split3(v[2], v[3], h1, m1, l1);
+                    }
+                    u32x2_t* o = A2 + (rb + PR * i) * 2;
+                    if constexpr (DIAG & 16) {
+                        if (h0 == 0x12345u && m1 == 0x54321u) o[0] = u32x2_t{l0, l1};
+                    } else {
                     o[0] = u32x2_t{h0, h1};
                     o[4 * OSA * 2] = u32x2_t{m0, m1};
                     o[8 * OSA * 2] = u32x2_t{l0, l1};
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < IB; ++i) {
@@ -168,12 +191,21 @@ __global__ __launch_bounds__(64 * (WA * WB + 4)) void wgrad_pw_kernel(WgPwDesc d
                         if (brow_off[i] == OOB) { v[0] = v[1] = v[2] = v[3] = 0.f; }
                     }
                     uint32_t h0, m0, l0, h1, m1, l1;
-                    split3(v[0], v[1], h0, m0, l0);
-                    split3(v[2], v[3], h1, m1, l1);
-                    u32x2_t* o = B2 + (rb + 32 * i) * 2;
+                    if constexpr (DIAG & 2) {
+                        h0 = __float_as_uint(v[0]); m0 = __float_as_uint(v[1]); l0 = h0 ^ m0;
+                        h1 = __float_as_uint(v[2]); m1 = __float_as_uint(v[3]); l1 = h1 ^ m1;
+                    } else {
+                        split3(v[0], v[1], h0, m0, l0);
+                        split3(v[2], v[3], h1, m1, l1);
+                    }
+                    u32x2_t* o = B2 + (rb + PR * i) * 2;
+                    if constexpr (DIAG & 16) {
+                        if (h0 == 0x12345u && m1 == 0x54321u) o[0] = u32x2_t{l0, l1};
+                    } else {
                     o[0] = u32x2_t{h0, h1};
                     o[4 * OSB * 2] = u32x2_t{m0, m1};
                     o[8 * OSB * 2] = u32x2_t{l0, l1};
+                    }
                 }
             };
             // almost every stage is whole (4 live pixels in every quad): a wave-uniform test picks the body without selects
@@ -210,12 +242,30 @@ __global__ __launch_bounds__(64 * (WA * WB + 4)) void wgrad_pw_kernel(WgPwDesc d
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int afrag = lh * OSA + wa * 64 + l31, bfrag = 12 * OSA + lh * OSB + wb * 64 + l31;
     auto lda = [&](u32x4 (&f)[3], const u32x4* cur, int t, int blk) {
+        if constexpr (DIAG & 8) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f[p] = u32x4{(uint32_t)(t + blk), 0x3f803f80u, (uint32_t)p, 0x3f803f80u};
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 3; ++p) f[p] = cur[afrag + (p * 4 + 2 * t) * OSA + 32 * blk];
     };
     auto ldb = [&](u32x4 (&f)[3], const u32x4* cur, int t, int blk) {
+        if constexpr (DIAG & 8) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f[p] = u32x4{(uint32_t)(t * 2 + blk), 0x3f803f80u, (uint32_t)p, 0x3f803f80u};
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 3; ++p) f[p] = cur[bfrag + (p * 4 + 2 * t) * OSB + 32 * blk];
+    };
+    auto mm = [&](const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 c) {
+        if constexpr (DIAG & 4) {
+            c[0] += __uint_as_float(a[0].x ^ b[0].y ^ a[1].z ^ b[1].w ^ a[2].x ^ b[2].y);
+            return c;
+        } else {
+            return mfma_split(a, b, c);
+        }
     };
     __syncthreads();
     u32x4 a0[3], a1[3], b0[3], b1[3];
@@ -226,40 +276,63 @@ __global__ __launch_bounds__(64 * (WA * WB + 4)) void wgrad_pw_kernel(WgPwDesc d
         ldb(b1, cur, 0, 1);
         lda(a1, cur, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        acc[0][0] = mfma_split(a0, b0, acc[0][0]);
-        acc[0][1] = mfma_split(a0, b1, acc[0][1]);
+        acc[0][0] = mm(a0, b0, acc[0][0]);
+        acc[0][1] = mm(a0, b1, acc[0][1]);
         __builtin_amdgcn_sched_barrier(0);
         lda(a0, cur, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        acc[1][0] = mfma_split(a1, b0, acc[1][0]);
+        acc[1][0] = mm(a1, b0, acc[1][0]);
         __builtin_amdgcn_sched_barrier(0);
         ldb(b0, cur, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        acc[1][1] = mfma_split(a1, b1, acc[1][1]);
+        acc[1][1] = mm(a1, b1, acc[1][1]);
         __builtin_amdgcn_sched_barrier(0);
         ldb(b1, cur, 1, 1);
         lda(a1, cur, 1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        acc[0][0] = mfma_split(a0, b0, acc[0][0]);
-        acc[0][1] = mfma_split(a0, b1, acc[0][1]);
-        acc[1][0] = mfma_split(a1, b0, acc[1][0]);
-        acc[1][1] = mfma_split(a1, b1, acc[1][1]);
+        acc[0][0] = mm(a0, b0, acc[0][0]);
+        acc[0][1] = mm(a0, b1, acc[0][1]);
+        acc[1][0] = mm(a1, b0, acc[1][0]);
+        acc[1][1] = mm(a1, b1, acc[1][1]);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
     store_tile<2, 2, RA, RB, WA, WB>(acc, dc, d.Cout, d.Cin, i0, j0, z);
 }
 
-template <int WA, int WB, bool TF, bool DSA, bool RAG>
+static int wg_pw_np() {        // SCAT_WGPW_NP=8: eight producer wavefronts with the eight-consumer tiles (1024 threads)
+    static const int m = [] { const char* e = getenv("SCAT_WGPW_NP"); return e ? atoi(e) : 4; }();
+    return m;
+}
+
+template <int WA, int WB, bool TF, bool DSA, bool RAG, int DIAG = 0, int NP = 4>
 static void launch_wg_pw(const WgPwDesc& d, const OutDesc& dc, int splits, hipStream_t st) {
+    if constexpr (NP == 4 && DIAG == 0 && WA * WB == 8 && !DSA) {
+        if (wg_pw_np() == 8) return launch_wg_pw<WA, WB, TF, DSA, RAG, 0, 8>(d, dc, splits, st);
+    }
     constexpr int RA = 64 * WA, RB = 64 * WB;
     const int mt = cdiv(d.Cout, RA), nt = cdiv(d.Cin, RB);
     constexpr size_t lds_bytes = (size_t)2 * 12 * (RA + 8 + RB + 8) * 16;
-    auto kern = wgrad_pw_kernel<WA, WB, TF, DSA, RAG>;
+#ifdef SCAT_DIAG
+    if constexpr (DIAG == 0 && !TF && !DSA && !RAG && WA * WB == 8) {     // ablation variants: SCAT_TUNE = 200 + DIAG
+        switch (tuning() - 200) {
+        case 1: return launch_wg_pw<WA, WB, TF, DSA, RAG, 1>(d, dc, splits, st);
+        case 2: return launch_wg_pw<WA, WB, TF, DSA, RAG, 2>(d, dc, splits, st);
+        case 3: return launch_wg_pw<WA, WB, TF, DSA, RAG, 3>(d, dc, splits, st);
+        case 4: return launch_wg_pw<WA, WB, TF, DSA, RAG, 4>(d, dc, splits, st);
+        case 8: return launch_wg_pw<WA, WB, TF, DSA, RAG, 8>(d, dc, splits, st);
+        case 12: return launch_wg_pw<WA, WB, TF, DSA, RAG, 12>(d, dc, splits, st);
+        case 16: return launch_wg_pw<WA, WB, TF, DSA, RAG, 16>(d, dc, splits, st);
+        case 19: return launch_wg_pw<WA, WB, TF, DSA, RAG, 19>(d, dc, splits, st);
+        default: break;
+        }
+    }
+#endif
+    auto kern = wgrad_pw_kernel<WA, WB, TF, DSA, RAG, DIAG, NP>;
     static bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes) == hipSuccess);
     (void)once;
-    hipLaunchKernelGGL(kern, dim3(mt * nt, 1, splits), dim3(64 * (WA * WB + 4)), lds_bytes, st, d, dc);
+    hipLaunchKernelGGL(kern, dim3(splitk_xcd_grid(mt * nt, splits, d.ngroup)), dim3(64 * (WA * WB + NP)), lds_bytes, st, d, dc);
 }
 
 template <int WA, int WB, bool DSA>
@@ -314,7 +387,8 @@ void wgrad_pw_launch(const WgPwPlan& p, const float* dy, const float* x, float* 
     d.dy = dy; d.x = x; d.scale = in_scale; d.shift = in_shift; d.dy2 = dy2; d.coef = coef3;
     d.relu = in_scale ? in_relu : 0;
     d.Cout = Cout; d.Cin = Cin; d.HW = HW;
-    d.NO = (HW + 7) / 8; d.U = B * d.NO; d.NS = p.stages; d.spz = p.spz;
+    d.NO = (HW + 7) / 8; d.U = B * d.NO; d.NS = p.stages; d.spz = p.spz; d.nsplit = p.splits;
+    d.ngroup = splitk_xcd_groups(p.splits);
     d.dNO = FastDiv::make(d.NO);
     d.ndy = (int64_t)B * Cout * HW; d.nx = (int64_t)B * Cin * HW;
     OutDesc dc{};

@@ -36,6 +36,7 @@ struct RowWgDesc {
     int nov;              // octets that hold pixels: ceil(W / 8)
     FastDiv dH;
     int64_t ndy, nx;
+    int ntile, nsplit, ngroup;   // XCD-local split-K mapping
     int stamp;            // diag build only (SCAT_WG_ROWS_STAMP, tools/rows_stamp.py): results are overwritten by time stamps
 };
 
@@ -50,7 +51,10 @@ __global__ __launch_bounds__(RW_NT) void wgrad3x3_rows_kernel(RowWgDesc d) {
     u32x4* const DY = L + 4 * XS;                   // 2 dy buffers
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int cb = blockIdx.x % d.ncb, mb = blockIdx.x / d.ncb, z = blockIdx.z;
+    // the tiles of one row-range slice read the same rows of dy and x: one XCD (splitk_xcd_map, conv_common.h)
+    int tile_, z;
+    if (!splitk_xcd_map(blockIdx.x, d.ntile, d.nsplit, d.ngroup, tile_, z)) return;
+    const int cb = tile_ % d.ncb, mb = tile_ / d.ncb;
     const int g0 = z * d.rpw, g1 = min(g0 + d.rpw, d.rows);
     const int N = d.Cin * 9;
 
@@ -262,6 +266,7 @@ struct RowWg64Desc {
     int relu;
     int B, Cin, Cout, H, W;
     int rows, rpw, ncb, noct, nov, rpi;
+    int ntile, nsplit, ngroup;   // XCD-local split-K mapping
     FastDiv dH;
     int64_t ndy, nx;
 };
@@ -277,7 +282,10 @@ __global__ __launch_bounds__(512) void wgrad3x3_rows64_kernel(RowWg64Desc d) {
     u32x4* const DY = L + NX * XS;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int cb = blockIdx.x % d.ncb, mb = blockIdx.x / d.ncb, z = blockIdx.z;
+    // the tiles of one row-range slice read the same rows of dy and x: one XCD (splitk_xcd_map, conv_common.h)
+    int tile_, z;
+    if (!splitk_xcd_map(blockIdx.x, d.ntile, d.nsplit, d.ngroup, tile_, z)) return;
+    const int cb = tile_ % d.ncb, mb = tile_ / d.ncb;
     const int g0 = z * d.rpw, g1 = min(g0 + d.rpw, d.rows);
     const int N = d.Cin * 9;
     const int nit = (g1 - g0 + RPI - 1) / RPI;
@@ -520,7 +528,8 @@ int wgrad_rows_launch(const float* dy, const float* x, float* slab, int B, int C
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 2 * 64 * 16) == hipSuccess);
         (void)once1; (void)once2;
         set_kernel_label("wgrad3x3_rows_64x576x16%s_r%d_split%d", in_scale ? "_tf" : "", rpi, splits);
-        const dim3 grid(d.ncb * (Cout / 64), 1, splits);
+        d.ntile = d.ncb * (Cout / 64); d.nsplit = splits; d.ngroup = splitk_xcd_groups(splits);
+        const dim3 grid(splitk_xcd_grid(d.ntile, splits, d.ngroup));
         if (rpi == 2) hipLaunchKernelGGL(wgrad3x3_rows64_kernel<2>, grid, dim3(512), lds_bytes, st, d);
         else hipLaunchKernelGGL(wgrad3x3_rows64_kernel<1>, grid, dim3(512), lds_bytes, st, d);
         return splits;
@@ -539,7 +548,8 @@ int wgrad_rows_launch(const float* dy, const float* x, float* slab, int B, int C
                                             (int)((4 * 3 + 2 * 9) * 8 * 32 * 16)) == hipSuccess);
     (void)once;
     set_kernel_label("wgrad3x3_rows_32x288x16%s_split%d", in_scale ? "_tf" : "", splits);
-    hipLaunchKernelGGL(wgrad3x3_rows_kernel, dim3(d.ncb * (Cout / 32), 1, splits), dim3(RW_NT), lds_bytes, st, d);
+    d.ntile = d.ncb * (Cout / 32); d.nsplit = splits; d.ngroup = splitk_xcd_groups(splits);
+    hipLaunchKernelGGL(wgrad3x3_rows_kernel, dim3(splitk_xcd_grid(d.ntile, splits, d.ngroup)), dim3(RW_NT), lds_bytes, st, d);
     return splits;
 }
 

@@ -21,15 +21,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {   // round-to-nearest-even, element 0 in the low half
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2_t));
 }
-// (the two subtractions of a pair as ONE packed fp32 operation, v_pk_add_f32: 9 instead of 11 vector instructions per
-// pair — beside a busy matrix pipe every staging instruction is time taken from the MFMAs)
+// Scalar subtractions on purpose: beside a busy matrix pipe a packed fp32 instruction (v_pk_add_f32) costs ~17 issue
+// cycles against 4 for a scalar one (MI355X_MICROARCH.md, "price of one filler beside MFMAs": "an anti-lever ... including
+// when the compiler SLP-packs adjacent scalar f32 adds") — the library is built with -fno-slp-vectorize for the same reason.
 __device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    f32x2 v = {a, b};
-    hi = pk_bf16(v[0], v[1]);
-    v -= f32x2{__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
-    mid = pk_bf16(v[0], v[1]);
-    v -= f32x2{__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
-    lo = pk_bf16(v[0], v[1]);
+    hi = pk_bf16(a, b);
+    a -= __uint_as_float(hi << 16);
+    b -= __uint_as_float(hi & 0xffff0000u);
+    mid = pk_bf16(a, b);
+    a -= __uint_as_float(mid << 16);
+    b -= __uint_as_float(mid & 0xffff0000u);
+    lo = pk_bf16(a, b);
 }
 // 8 floats -> the three 16-byte fragments
 __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
