@@ -214,6 +214,13 @@ def instantiation_of(label, traffic=None):
     m = re.match(r"conv3x3_split_(\d+)x(\d+)x16", label)
     if m:
         return f"conv3x3_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf}>"
+    m = re.match(r"wgrad1x1_pw_(\d+)x(\d+)x32", label)
+    if m:       # second-generation pointwise weight gradient: WA x WB consumer wavefronts of 64 x 64
+        rag = "t" if "_rag" in label else "f"
+        return f"wgrad_pw_kernel<{int(m.group(1)) // 64},{int(m.group(2)) // 64},{tf},{ds},{rag},0,4>"
+    m = re.match(r"wgrad3x3_rows_64x576x16.*_r(\d)", label)
+    if m:
+        return f"wgrad3x3_rows64_kernel<{m.group(1)}>"
     if label.startswith("wgrad3x3_rows"):
         return "wgrad3x3_rows_kernel"
     if label.startswith("wgrad7x7_s2_split"):

@@ -129,7 +129,8 @@ def test_bench_roofline_lookup_matches_profiles():
     traffic, name = bench.latest_traffic()
     assert name is not None and traffic, "no profiles/r*_traffic.json"
     for label in ("conv1x1_split_128x128x32", "conv1x1_split_128x128x32_tf", "conv3x3_split_64x128x16",
-                  "wgrad1x1_split_pc128x128x16_split96", "wgrad3x3_split_pc128x128x16_tf_split86",
+                  "wgrad1x1_pw_128x256x32_split124", "wgrad1x1_pw_256x128x32_tf_split32", "wgrad1x1_pw_128x128x32_tf_bnb_split64",
+                  "wgrad3x3_rows_64x576x16_tf_r1_split64", "wgrad3x3_s2_split_pc128x128x16_tf_split86",
                   "conv7x7_s2_split_64x128x32"):
         inst = bench.instantiation_of(label, traffic)
         assert inst in traffic, (label, inst, sorted(traffic)[:8])

@@ -35,7 +35,7 @@ def main():
     write = mean_by_kernel(sys.argv[2], "WRITE_SIZE")
     out = {}
     for k in sorted(set(fetch) & set(write)):
-        if not any(t in k for t in ("gemm<", "split_kernel", "halo_kernel", "conv1x1_kernel", "pc_kernel", "rows_kernel", "vit_", "bn_")):
+        if not any(t in k for t in ("gemm<", "split_kernel", "halo_kernel", "conv1x1_kernel", "pc_kernel", "pw_kernel", "sk_kernel", "rows_kernel", "rows64_kernel", "vit_", "bn_")):
             continue
         f, n = fetch[k]
         w, _ = write[k]
