@@ -217,15 +217,31 @@ __global__ __launch_bounds__(64 * (WA * WB + NP)) void wgrad_pw_kernel(WgPwDesc 
         load_stage(sbeg + 1, S1{});
         store_stage(L0, S0{});
         __syncthreads();
+        unsigned long long tw = 0, tb0 = 0;                    // DIAG & 32: cycles parked at the stage barrier / loop start
         auto iter = [&](int k, auto par_tag) {
             constexpr int P = decltype(par_tag)::value;        // k & 1
             load_stage(sbeg + k + 2, par_tag);                 // its set was written to LDS an iteration ago
             store_stage(L0 + (P ^ 1) * BUF, std::integral_constant<int, P ^ 1>{});   // stage k+1, loaded an iteration ago
-            __syncthreads();
+            if constexpr (DIAG & 32) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                __syncthreads();
+                tw += __builtin_amdgcn_s_memtime() - t0;
+            } else {
+                __syncthreads();
+            }
         };
+        if constexpr (DIAG & 32) tb0 = __builtin_amdgcn_s_memtime();
         for (int k = 0; k < nst; k += 2) {
             iter(k, S0{});
             if (k + 1 < nst) iter(k + 1, S1{});
+        }
+        if constexpr (DIAG & 32) {
+            const unsigned long long tot = __builtin_amdgcn_s_memtime() - tb0;
+            __syncthreads();                                   // (pairs with the consumers' barrier behind their epilogue)
+            if (lane == 0) {
+                unsigned long long* o = (unsigned long long*)(dc.p + (int64_t)z * dc.sz + (int64_t)(i0 + wave) * dc.si + j0);
+                o[0] = tot; o[1] = tw;
+            }
         }
         return;
     }
@@ -269,6 +285,8 @@ __global__ __launch_bounds__(64 * (WA * WB + NP)) void wgrad_pw_kernel(WgPwDesc 
     };
     __syncthreads();
     u32x4 a0[3], a1[3], b0[3], b1[3];
+    unsigned long long tw = 0, tb0 = 0;
+    if constexpr (DIAG & 32) tb0 = __builtin_amdgcn_s_memtime();
     for (int k = 0; k < nst; ++k) {
         const u32x4* cur = L0 + (k & 1) * BUF;
         lda(a0, cur, 0, 0);
@@ -295,9 +313,24 @@ __global__ __launch_bounds__(64 * (WA * WB + NP)) void wgrad_pw_kernel(WgPwDesc 
         acc[1][0] = mm(a1, b0, acc[1][0]);
         acc[1][1] = mm(a1, b1, acc[1][1]);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        if constexpr (DIAG & 32) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            tw += __builtin_amdgcn_s_memtime() - t0;
+        } else {
+            __syncthreads();
+        }
     }
     store_tile<2, 2, RA, RB, WA, WB>(acc, dc, d.Cout, d.Cin, i0, j0, z);
+    if constexpr (DIAG & 32) {      // every wavefront leaves (loop cycles, cycles parked at the barrier) in row i0 + wave
+        const unsigned long long tot = __builtin_amdgcn_s_memtime() - tb0;
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (lane == 0) {
+            unsigned long long* o = (unsigned long long*)(dc.p + (int64_t)z * dc.sz + (int64_t)(i0 + wave) * dc.si + j0);
+            o[0] = tot; o[1] = tw;
+        }
+    }
 }
 
 static int wg_pw_np() {        // SCAT_WGPW_NP=8: eight producer wavefronts with the eight-consumer tiles (1024 threads)
@@ -324,6 +357,7 @@ static void launch_wg_pw(const WgPwDesc& d, const OutDesc& dc, int splits, hipSt
         case 12: return launch_wg_pw<WA, WB, TF, DSA, RAG, 12>(d, dc, splits, st);
         case 16: return launch_wg_pw<WA, WB, TF, DSA, RAG, 16>(d, dc, splits, st);
         case 19: return launch_wg_pw<WA, WB, TF, DSA, RAG, 19>(d, dc, splits, st);
+        case 32: return launch_wg_pw<WA, WB, TF, DSA, RAG, 32>(d, dc, splits, st);
         default: break;
         }
     }
