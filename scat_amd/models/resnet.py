@@ -85,6 +85,7 @@ BNB1_MIN_H = int(os.environ.get("SCAT_BNB1_MIN_H", "0"))
 BNB_MIN_H = int(os.environ.get("SCAT_BNB_MIN_H", "28"))   # fold bn3 only where it pays: 56x56 and 28x28 planes (tools/bnb_bench.py: at 14x14 the dual-source kernels cost more than the pass they save)
 BNB = os.environ.get("SCAT_BNB", "1") != "0"   # fold bn3's backward apply into conv3's gradient kernels
 SUBSAMPLE = os.environ.get("SCAT_SUBSAMPLE", "1") != "0"   # pack the input of the 1x1/stride-2 shortcuts (stride-1 kernels)
+SIDE_SHORTCUT = os.environ.get("SCAT_SIDE_SHORTCUT", "1") != "0"   # forward: the shortcut convolution beside conv1..conv3 (own stream)
 SIDE_WGRAD = os.environ.get("SCAT_SIDE_WGRAD", "1") != "0"   # bench.py clears it for its serialized, per-kernel-timed step
 
 
@@ -104,13 +105,7 @@ def _block_forward(blk, xin, training, wp=None):
     """Bottleneck.forward (models/resnet.py:78-98) as a kernel sequence -> tape record
     (blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out, omask).  bn1/bn2's normalise+ReLU live in the operand load of
     the next convolution; bn3 (+ the shortcut's BatchNorm) + residual + ReLU is the one pass that writes the output."""
-    c1 = ops.conv2d_fwd(xin, blk.conv1.weight, 1, 0, wp=wp, stats=training)
-    s1 = _BNState(c1, blk.bn1, training)
-    c2 = ops.conv2d_fwd(c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True, wp=wp, stats=training)
-    s2 = _BNState(c2, blk.bn2, training)
-    c3 = ops.conv2d_fwd(c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True, wp=wp, stats=training)
-    s3 = _BNState(c3, blk.bn3, training)
-    if blk.downsample is not None:
+    def shortcut():
         # stride-2 shortcut: pack the pixels it reads once, then it (and its weight gradient) is a
         # stride-1 pointwise convolution
         xs = ops.subsample2(xin) if blk.stride == 2 and SUBSAMPLE else None
@@ -120,9 +115,36 @@ def _block_forward(blk, xin, training, wp=None):
             cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0, wp=wp, stats=training)
         sd = _BNState(cd, blk.downsample[1], training)
         sd.xs = xs if training else None
+        return cd, sd
+
+    cd = sd = None
+    side = _side_stream(xin.device) if (blk.downsample is not None and SIDE_SHORTCUT and xin.is_cuda) else None
+    if side is not None:
+        # The forward is one dependent chain (every convolution waits for the previous one's batch statistics): the
+        # shortcut convolution of a stage's first block depends on the block input only, so it runs on the (otherwise
+        # idle) weight-gradient stream beside conv1..conv3 and fills their tails.  Its tensors are allocated while that
+        # stream is current: record_stream tells the caching allocator that the main stream uses them too.
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            cd, sd = shortcut()
+        xin.record_stream(side)
+    c1 = ops.conv2d_fwd(xin, blk.conv1.weight, 1, 0, wp=wp, stats=training)
+    s1 = _BNState(c1, blk.bn1, training)
+    c2 = ops.conv2d_fwd(c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True, wp=wp, stats=training)
+    s2 = _BNState(c2, blk.bn2, training)
+    c3 = ops.conv2d_fwd(c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True, wp=wp, stats=training)
+    s3 = _BNState(c3, blk.bn3, training)
+    if blk.downsample is not None:
+        if side is not None:
+            main.wait_stream(side)
+            for t in (cd, sd.scale, sd.shift, sd.mean, sd.invstd, sd.xs):
+                if t is not None:
+                    t.record_stream(main)
+        else:
+            cd, sd = shortcut()
         res, rsc, rsh = cd, sd.scale, sd.shift      # the shortcut's BatchNorm is applied while adding
     else:
-        cd = sd = None
         res, rsc, rsh = xin, None, None
     if training:    # the backward wants only the sign of the block output: keep 1 bit per element for it
         out, omask = ops.bn_apply(c3, s3.scale, s3.shift, res, True, want_mask=True, res_scale=rsc, res_shift=rsh)
