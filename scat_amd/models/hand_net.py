@@ -51,6 +51,18 @@ class PositionalEncoding(nn.Module):
         return _TokensFn.apply(x, self.pe[0], None, None)
 
 
+_ONES = {}
+
+
+def _ones_like(t):
+    """a cached all-ones tensor (the cotangent of ``sum(feat_out)``, hand_net.py:396): one fill per shape, not per step"""
+    key = (tuple(t.shape), t.dtype, str(t.device))
+    o = _ONES.get(key)
+    if o is None:
+        o = _ONES[key] = torch.ones_like(t)
+    return o
+
+
 def _upload_indices(idx, device):
     """int32 index tensor on ``device`` without making the host wait: ``torch.tensor(list, device=cuda)`` copies from
     pageable memory, which synchronises the stream — in the middle of the step (after the backbone forward) that
@@ -295,7 +307,7 @@ class EncoderTransformerCoarse(nn.Module):
                 feat_visual = tokens.view_as(feat_visual)
             pl_term = None
             if self.pl:
-                dtok = self.transformer.input_grad(torch.ones_like(feat_out))
+                dtok = self.transformer.input_grad(_ones_like(feat_out))
                 if aliased:
                     pl_term = dtok.contiguous().view_as(feat_visual)
                 else:
@@ -383,7 +395,7 @@ class EncoderTransformer(nn.Module):
         if self.pl:
             # d sum(feat_out) / d feat_visual, no graph (hand_net.py:396): replay the mixer tape for the
             # input gradient only, then undo the token scatter.
-            dtok = self.transformer.input_grad(torch.ones_like(feat_out))
+            dtok = self.transformer.input_grad(_ones_like(feat_out))
             if aliased:
                 pl_term = dtok.contiguous().view_as(feat_visual)
             else:
