@@ -196,9 +196,18 @@ int scat_bn_train_stats(const float* x, int B, int C, int HW, const float* gamma
  * host thread.  scat_bn_train_stats_partials sums the partials in fp64 in a fixed order and finishes as above. */
 int scat_epilogue_stats_arm(float* buf, int64_t bytes);
 int scat_epilogue_stats_groups(void);
+/* The same with a per-channel reference c[C] (device pointer, e.g. the previous step's batch mean): the kernel leaves the
+ * sums of (x - c) and (x - c)^2 instead — fp32 sums of x^2 over 32..128 pixels cancel catastrophically in
+ * E[x^2] - mean^2 when |mean| >> sigma — and scat_bn_train_stats_partials_shifted(partials, groups, c, ...) finishes
+ * mean = c + S1/N, var = S2/N - (S1/N)^2.  c must stay unchanged until that call has run. */
+int scat_epilogue_stats_arm_shift(float* buf, int64_t bytes, const float* shift);
 int scat_bn_train_stats_partials(const float* partials, int groups, int B, int C, int HW, const float* gamma,
                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                  float* save_mean, float* save_invstd, float* scale, float* shift, void* stream);
+int scat_bn_train_stats_partials_shifted(const float* partials, int groups, const float* stat_shift, int B, int C, int HW,
+                                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                         float momentum, float eps, float* save_mean, float* save_invstd, float* scale,
+                                         float* shift, void* stream);
 /* inference: scale/shift from running stats */
 int scat_bn_eval_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, int C, float* scale, float* shift, void* stream);

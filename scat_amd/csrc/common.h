@@ -23,7 +23,8 @@ void append_kernel_label(const char* suffix);
 // scat_epilogue_stats_arm: the next contraction launched from this thread may write per-tile row sums into the armed
 // buffer.  A launcher that supports it calls this with the rows and column groups of its grid: returns the buffer (and
 // records the group count for scat_epilogue_stats_groups) when one is armed and large enough, else nullptr.
-float* epi_stats_take(int rows, int groups);
+// *shift (optional out): the per-row reference the sums are taken about (scat_epilogue_stats_arm_shift), or nullptr
+float* epi_stats_take(int rows, int groups, const float** shift = nullptr);
 
 // Every entry point returns through these: no exception crosses the C boundary.
 #define SCAT_REQUIRE(cond, code, ...)          \

@@ -1233,7 +1233,7 @@ static void launch_pw_split(const PwDesc& d, const OutDesc& dc_in, hipStream_t s
     OutDesc dc = dc_in;
     if (!dc.accumulate && !dc.bias) {                 // a forward convolution: its BatchNorm's sums ride in the epilogue
         dc.sg = nt * (4 / WM);
-        dc.stats = epi_stats_take(d.M, dc.sg);
+        dc.stats = epi_stats_take(d.M, dc.sg, &dc.stats_shift);
     }
     if constexpr (!STEM && BN == 128) {
         // persistent stream-K grid when the caller armed a scratch buffer and the launch has enough tiles to share out

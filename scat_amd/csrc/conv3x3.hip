@@ -438,7 +438,7 @@ static void launch_split(const HaloDesc& d, const OutDesc& dc_in, hipStream_t st
     OutDesc dc = dc_in;
     if (!dc.accumulate && !dc.bias) {                 // a forward convolution: its BatchNorm's sums ride in the epilogue
         dc.sg = nt * (4 / WM);
-        dc.stats = epi_stats_take(d.M, dc.sg);
+        dc.stats = epi_stats_take(d.M, dc.sg, &dc.stats_shift);
     }
     auto kern = conv3x3_split_kernel<WM, HB_N, TF>;
     hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(NT), lds_bytes, st, d, dc);

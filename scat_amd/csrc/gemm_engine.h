@@ -73,6 +73,8 @@ struct OutDesc {
     float* stats;         // optional: per-row (sum, sum of squares) of every wavefront's live columns of the tile,
     int sg;               //   stats[(row * sg + group) * 2 + {0, 1}], group = tile column * WN + wn  (BatchNorm statistics
                           //   of a convolution's output without reading it back: scat_epilogue_stats_arm)
+    const float* stats_shift;   // optional per-row reference c[row]: the sums are of (x - c) and (x - c)^2 — fp32 partials of
+                                // x^2 cancel catastrophically in E[x^2] - mean^2 when |mean| >> sigma (scat_epilogue_stats_arm_shift)
 };
 
 // ---------------------------------------------------------------- loaders
@@ -483,10 +485,15 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[MI][NI], const OutDesc&
             float s[16], q[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                float cref = 0.f;
+                if (dc.stats_shift) {
+                    const int ir = ibase + a * 32 + (r & 3) + 8 * (r >> 2);
+                    cref = dc.stats_shift[ir < M ? ir : 0];
+                }
                 float ss = 0.f, qq = 0.f;
 #pragma unroll
                 for (int b = 0; b < NI; ++b) {
-                    const float v = colok[b] ? acc[a][b][r] : 0.f;
+                    const float v = colok[b] ? acc[a][b][r] - cref : 0.f;
                     ss += v;
                     qq = fmaf(v, v, qq);
                 }

@@ -32,13 +32,15 @@ void append_kernel_label(const char* suffix) {
     if (n + strlen(suffix) + 1 <= sizeof(g_label)) strcpy(g_label + n, suffix);
 }
 
-struct EpiStats { float* buf; int64_t cap; int groups; };
-static thread_local EpiStats g_epi = {nullptr, 0, 0};
-float* epi_stats_take(int rows, int groups) {
+struct EpiStats { float* buf; int64_t cap; int groups; const float* shift; };
+static thread_local EpiStats g_epi = {nullptr, 0, 0, nullptr};
+float* epi_stats_take(int rows, int groups, const float** shift) {
     float* b = g_epi.buf;
     g_epi.buf = nullptr;
+    if (shift) *shift = nullptr;
     if (!b || (int64_t)rows * groups * 2 > g_epi.cap) return nullptr;
     g_epi.groups = groups;
+    if (shift) *shift = g_epi.shift;
     return b;
 }
 
@@ -692,6 +694,12 @@ extern "C" int scat_epilogue_stats_arm(float* buf, int64_t bytes) {
     scat::g_epi.buf = buf;
     scat::g_epi.cap = buf ? bytes / 4 : 0;
     scat::g_epi.groups = 0;
+    scat::g_epi.shift = nullptr;
+    return SCAT_OK;
+}
+extern "C" int scat_epilogue_stats_arm_shift(float* buf, int64_t bytes, const float* shift) {
+    scat_epilogue_stats_arm(buf, bytes);
+    scat::g_epi.shift = buf ? shift : nullptr;
     return SCAT_OK;
 }
 extern "C" int scat_epilogue_stats_groups(void) {

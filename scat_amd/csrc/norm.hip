@@ -72,13 +72,25 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 }
 
 // statistics -> what forward and backward need of them (+ running-stat update, unbiased variance)
+__device__ __forceinline__ void bn_finish_mv(int c, double mean, double var, double count,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                             float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                             float* __restrict__ scale, float* __restrict__ shift);
 __device__ __forceinline__ void bn_finish(int c, double s1, double s2, double count, const float* __restrict__ gamma,
                                           const float* __restrict__ beta, float* __restrict__ rmean,
                                           float* __restrict__ rvar, float momentum, float eps,
                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                           float* __restrict__ scale, float* __restrict__ shift) {
-    double mean = s1 / count;
-    double var = s2 / count - mean * mean;
+    const double mean = s1 / count;
+    bn_finish_mv(c, mean, s2 / count - mean * mean, count, gamma, beta, rmean, rvar, momentum, eps, save_mean, save_invstd,
+                 scale, shift);
+}
+__device__ __forceinline__ void bn_finish_mv(int c, double mean, double var, double count,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                             float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                             float* __restrict__ scale, float* __restrict__ shift) {
     if (var < 0) var = 0;
     double invstd = 1.0 / sqrt(var + (double)eps);
     save_mean[c] = (float)mean;
@@ -151,7 +163,10 @@ __global__ __launch_bounds__(1024) void bn_stats_fin_kernel(const float* __restr
 
 // Statistics from the row sums a convolution's epilogue left behind (OutDesc::stats, gemm_engine.h store_tile):
 // part[c][G][2] = (sum, sum of squares) of channel c over column group g, fp32; summed here in fp64, fixed order.
+// (stat_shift: the partials are sums of (x - c) and (x - c)^2 about a per-channel reference c — mean = c + S1/N,
+// var = S2/N - (S1/N)^2, the same finish)
 __global__ __launch_bounds__(256) void bn_partials_fin_kernel(const float* __restrict__ part, int G, double count,
+                                                               const float* __restrict__ stat_shift,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ rmean,
                                                                float* __restrict__ rvar, float momentum, float eps,
@@ -168,8 +183,15 @@ __global__ __launch_bounds__(256) void bn_partials_fin_kernel(const float* __res
     }
     __shared__ double sh[8];
     block_sum2(s1, s2, sh);
-    if (threadIdx.x == 0)
-        bn_finish(c, s1, s2, count, gamma, beta, rmean, rvar, momentum, eps, save_mean, save_invstd, scale, shift);
+    if (threadIdx.x == 0) {
+        if (stat_shift) {
+            const double d1 = s1 / count;
+            bn_finish_mv(c, (double)stat_shift[c] + d1, s2 / count - d1 * d1, count, gamma, beta, rmean, rvar, momentum, eps,
+                         save_mean, save_invstd, scale, shift);
+        } else {
+            bn_finish(c, s1, s2, count, gamma, beta, rmean, rvar, momentum, eps, save_mean, save_invstd, scale, shift);
+        }
+    }
 }
 
 __global__ void bn_eval_fold_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
@@ -597,9 +619,29 @@ extern "C" int scat_bn_train_stats_partials(const float* partials, int groups, i
     SCAT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), SCAT_E_ARG,
                  "scat_bn_train_stats_partials: running pair");
     hipLaunchKernelGGL(bn_partials_fin_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, groups,
-                       (double)B * HW, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale,
-                       shift);
+                       (double)B * HW, (const float*)nullptr, gamma, beta, running_mean, running_var, momentum, eps,
+                       save_mean, save_invstd, scale, shift);
     SCAT_LAUNCH_CHECK("scat_bn_train_stats_partials");
+    return SCAT_OK;
+}
+
+extern "C" int scat_bn_train_stats_partials_shifted(const float* partials, int groups, const float* stat_shift, int B,
+                                                    int C, int HW, const float* gamma, const float* beta,
+                                                    float* running_mean, float* running_var, float momentum, float eps,
+                                                    float* save_mean, float* save_invstd, float* scale, float* shift,
+                                                    void* stream) {
+    SCAT_REQUIRE(partials && stat_shift && gamma && beta && save_mean && save_invstd && scale && shift, SCAT_E_ARG,
+                 "scat_bn_train_stats_partials_shifted: null pointer");
+    SCAT_REQUIRE(groups > 0 && B > 0 && C > 0 && HW > 0, SCAT_E_SHAPE,
+                 "scat_bn_train_stats_partials_shifted: non-positive dimension");
+    SCAT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), SCAT_E_ARG,
+                 "scat_bn_train_stats_partials_shifted: running pair");
+    SCAT_REQUIRE(stat_shift != save_mean, SCAT_E_ARG,
+                 "scat_bn_train_stats_partials_shifted: the reference must not be the buffer the new mean is written to");
+    hipLaunchKernelGGL(bn_partials_fin_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, groups,
+                       (double)B * HW, stat_shift, gamma, beta, running_mean, running_var, momentum, eps, save_mean,
+                       save_invstd, scale, shift);
+    SCAT_LAUNCH_CHECK("scat_bn_train_stats_partials_shifted");
     return SCAT_OK;
 }
 

@@ -64,6 +64,7 @@ class _BNState:
         if training:
             self.mean, self.invstd, self.scale, self.shift = ops.bn_train_stats(
                 x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+            bn._stat_ref = self.mean       # next step's reference for the epilogue sums (ops.conv2d_fwd stats_shift)
             _NBT.append(bn.num_batches_tracked)
             bn._fold_cache = None          # running statistics move (by a raw kernel: no version bump)
         else:
@@ -101,6 +102,15 @@ def _side_stream(device, who="backbone"):
     return _SIDE[key]
 
 
+STAT_REF = os.environ.get("SCAT_STAT_REF", "1") != "0"   # epilogue BatchNorm sums about the previous step's batch mean
+
+
+def _ref(bn):
+    """the reference the convolution epilogue takes its BatchNorm sums about: the previous training step's batch mean of
+    this BatchNorm (None on the first step: plain sums)"""
+    return getattr(bn, "_stat_ref", None) if STAT_REF else None
+
+
 def _block_forward(blk, xin, training, wp=None):
     """Bottleneck.forward (models/resnet.py:78-98) as a kernel sequence -> tape record
     (blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out, omask).  bn1/bn2's normalise+ReLU live in the operand load of
@@ -110,9 +120,11 @@ def _block_forward(blk, xin, training, wp=None):
         # stride-1 pointwise convolution
         xs = ops.subsample2(xin) if blk.stride == 2 and SUBSAMPLE else None
         if xs is not None:
-            cd = ops.conv2d_fwd(xs, blk.downsample[0].weight, 1, 0, wp=wp, stats=training)
+            cd = ops.conv2d_fwd(xs, blk.downsample[0].weight, 1, 0, wp=wp, stats=training,
+                                stats_shift=_ref(blk.downsample[1]))
         else:
-            cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0, wp=wp, stats=training)
+            cd = ops.conv2d_fwd(xin, blk.downsample[0].weight, blk.stride, 0, wp=wp, stats=training,
+                                stats_shift=_ref(blk.downsample[1]))
         sd = _BNState(cd, blk.downsample[1], training)
         sd.xs = xs if training else None
         return cd, sd
@@ -129,11 +141,13 @@ def _block_forward(blk, xin, training, wp=None):
         with torch.cuda.stream(side):
             cd, sd = shortcut()
         xin.record_stream(side)
-    c1 = ops.conv2d_fwd(xin, blk.conv1.weight, 1, 0, wp=wp, stats=training)
+    c1 = ops.conv2d_fwd(xin, blk.conv1.weight, 1, 0, wp=wp, stats=training, stats_shift=_ref(blk.bn1))
     s1 = _BNState(c1, blk.bn1, training)
-    c2 = ops.conv2d_fwd(c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True, wp=wp, stats=training)
+    c2 = ops.conv2d_fwd(c1, blk.conv2.weight, blk.stride, 1, s1.scale, s1.shift, True, wp=wp, stats=training,
+                        stats_shift=_ref(blk.bn2))
     s2 = _BNState(c2, blk.bn2, training)
-    c3 = ops.conv2d_fwd(c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True, wp=wp, stats=training)
+    c3 = ops.conv2d_fwd(c2, blk.conv3.weight, 1, 0, s2.scale, s2.shift, True, wp=wp, stats=training,
+                        stats_shift=_ref(blk.bn3))
     s3 = _BNState(c3, blk.bn3, training)
     if blk.downsample is not None:
         if side is not None:
@@ -340,7 +354,7 @@ class _BackboneFn(torch.autograd.Function):
         if part != 2:
             wp.run(training)       # one launch re-lays every convolution weight for this step (ops.WeightPrep)
             # stem: conv7x7/2 -> [BN -> ReLU -> maxpool fused]
-            c0 = ops.conv2d_fwd(x, net.conv1.weight, 2, 3, stats=training)
+            c0 = ops.conv2d_fwd(x, net.conv1.weight, 2, 3, stats=training, stats_shift=_ref(net.bn1))
             s0 = _BNState(c0, net.bn1, training)
             cur, idx0 = ops.maxpool_fwd(c0, s0.scale, s0.shift, True)
         else:

@@ -261,7 +261,7 @@ EPI_STATS = os.environ.get("SCAT_EPI_STATS", "1") != "0"   # BatchNorm sums in t
 
 
 def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, bias=None, out=None, wp=None,
-               stats=False):
+               stats=False, stats_shift=None):
     """wp: the network's WeightPrep (prepared weights), or None: the call re-lays its weights itself.
     stats: a training-mode BatchNorm follows — ask the kernel to leave the per-tile channel sums of its output behind
     (include/scat_hip.h scat_epilogue_stats_arm); ``y.scat_stats`` = (partials, groups) when it did, for
@@ -273,7 +273,15 @@ def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, b
     OH, OW = conv_out_hw(H, W, KH, stride, pad)
     nbytes = Cout * ((B * OH * OW + 31) // 32 + 4) * 8      # a column group is >= 32 pixels; + the ragged last tile
     part = workspace(nbytes, x.device, "bnpart")
-    lib().scat_epilogue_stats_arm(_p(part), nbytes)
+    # stats_shift[Cout] (optional): a per-channel reference the sums are taken about — the previous step's batch mean
+    # (resnet._BNState keeps it): fp32 partial sums of x^2 cancel in E[x^2] - mean^2 when |mean| >> sigma
+    if stats_shift is not None and not (stats_shift.device == x.device and stats_shift.dtype == torch.float32
+                                        and stats_shift.is_contiguous() and stats_shift.numel() == Cout):
+        stats_shift = None
+    if stats_shift is not None:
+        lib().scat_epilogue_stats_arm_shift(_p(part), nbytes, _p(stats_shift))
+    else:
+        lib().scat_epilogue_stats_arm(_p(part), nbytes)
     try:
         y = _conv2d_fwd(x, w, stride, pad, in_scale, in_shift, in_relu, bias, out, wp)
     finally:
@@ -282,7 +290,7 @@ def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, b
     # Protocol (same host thread): arm -> convolution -> groups() -> [bn_train_stats takes them]; any other armed
     # convolution in between bumps the generation and bn_train_stats falls back to the pass over y.
     _EPI_GEN[0] += 1
-    y.scat_stats = (part, groups, _EPI_GEN[0]) if groups > 0 else None
+    y.scat_stats = (part, groups, _EPI_GEN[0], stats_shift) if groups > 0 else None
     return y
 
 
@@ -521,11 +529,16 @@ def bn_train_stats(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=
     if st is not None and st[2] != _EPI_GEN[0]:
         st = x.scat_stats = None       # another convolution has used the workspace since: take the pass over x
     if st is not None:
-        part, groups, _ = st
+        part, groups, _, sshift = st
         x.scat_stats = None            # one use: the workspace behind it is recycled by the next convolution
-        _prof_hbm("bn_train_stats_partials", 8.0 * C * groups, lib().scat_bn_train_stats_partials, _p(part), groups, B, C,
-                  H * W, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps, _p(o[0]), _p(o[1]),
-                  _p(o[2]), _p(o[3]), _stream())
+        if sshift is not None:
+            _prof_hbm("bn_train_stats_partials", 8.0 * C * groups, lib().scat_bn_train_stats_partials_shifted, _p(part),
+                      groups, _p(sshift), B, C, H * W, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum,
+                      eps, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _stream())
+        else:
+            _prof_hbm("bn_train_stats_partials", 8.0 * C * groups, lib().scat_bn_train_stats_partials, _p(part), groups,
+                      B, C, H * W, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps, _p(o[0]),
+                      _p(o[1]), _p(o[2]), _p(o[3]), _stream())
         return o[0], o[1], o[2], o[3]
     ws = workspace(lib().scat_bn_ws(B, C, H * W), x.device)
     # algorithmic traffic: one read of x

@@ -518,6 +518,37 @@ def test_conv_epilogue_batchnorm_statistics(ops, B, cin, cout, k, s, p, H, W):
     assert rel_err(scale, scale2.cpu()) < 2e-6 and rel_err(shift, shift2.cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("k,cin,cout,H", [(1, 64, 256, 28), (3, 64, 64, 28)])
+def test_conv_epilogue_statistics_with_large_channel_offsets(ops, k, cin, cout, H):
+    """the epilogue leaves fp32 sums of x and x^2 over 32..128 pixels; with |mean| ~ 100 sigma (an input
+    with a DC level) the variance E[x^2] - mean^2 formed from them has lost four digits.  Taken about a per-channel
+    reference (``stats_shift``: in the network the previous step's batch mean) the sums are of (x - c), (x - c)^2 and
+    the statistics are as accurate as the fp64 pass over the output again."""
+    B = 8
+    gen = torch.Generator().manual_seed(77 + k)
+    x = 1.0 + 0.01 * torch.randn((B, cin, H, H), generator=gen)
+    w = torch.randn((cout, cin, k, k), generator=gen) * (1.0 / (cin * k * k)) ** 0.5
+    y_ref = F.conv2d(x.double(), w.double(), padding=k // 2)
+    inner = y_ref[:, :, 2:-2, 2:-2]                                   # (the offset/sigma ratio away from the zero padding)
+    assert float((inner.mean(dim=(0, 2, 3)).abs() / inner.std(dim=(0, 2, 3))).median()) > 30
+    mean_ref = y_ref.mean(dim=(0, 2, 3))
+    invstd_ref = 1.0 / torch.sqrt(y_ref.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    ones, zeros = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+
+    def run(shift):
+        y = ops.conv2d_fwd(g(x), g(w), 1, k // 2, stats=True, stats_shift=shift)
+        assert getattr(y, "scat_stats", None) is not None
+        mean, invstd, _, _ = ops.bn_train_stats(y, ones, zeros, zeros.clone(), ones.clone())
+        return rel_err(mean, mean_ref), rel_err(invstd, invstd_ref)
+
+    e_plain = run(None)
+    ref = g(mean_ref.float() * (1.0 + 1e-3))                          # "last step's mean": close to, not equal to, this one
+    e_ref = run(ref)
+    assert e_ref[0] < 2e-6 and e_ref[1] < 2e-5, (e_ref, e_plain)
+    if k == 1:                                                         # (no padding: every pixel carries the offset)
+        assert e_plain[1] > 10 * e_ref[1], (e_ref, e_plain)           # the reference is what makes the difference
+
+
 def test_batchnorm_sign_mask(ops):
     """bn_bwd from the 1-bit sign mask of the block output == bn_bwd from the output itself, bit for bit."""
     B, C, H = 3, 64, 28
