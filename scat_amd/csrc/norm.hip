@@ -3,6 +3,8 @@
 // fixed order (two-stage, no atomics) so results are bitwise reproducible run to run.
 // Reference: nn.BatchNorm2d at models/resnet.py:68-73,108,131; nn.LayerNorm at
 // models/vision_transformer.py:20-26.
+#include <atomic>
+
 #include "common.h"
 
 namespace scat {
@@ -31,22 +33,93 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
     }
 }
 
+// ---------------------------------------------------------------- finalize by the last arriver, no second launch
+//
+// A per-channel reduction over S workgroups followed by a per-channel finalize used to be two launches, the second a few
+// microseconds of work behind a full launch boundary on the critical path (22 of them in a ResNet-50 backward, 512 in an
+// HRNet-W32 step).  Now every workgroup publishes its partial {s1, s2, tag} with agent-coherent (sc1, write-through)
+// stores — data, wait, tag, wait — and then looks at the tags of all S slots of its channel with sc1 loads: the workgroup
+// whose publication completed last necessarily sees them all (MI355X guide, Guideline 16: sc1 stores need no release
+// fence, sc1 loads no acquire; no buffer_wbl2 anywhere — the device-scope fence of a first attempt at this cost 2.7 ms
+// per step).  Several workgroups may see a complete channel; an atomic exchange on a claim word picks exactly one (the
+// running statistics are updated in place, so the finish must run once).  `tag` is unique per launch: slots and claim
+// words live in a recycled workspace and are never cleared.  The sum runs over the slots in index order: same bits as the
+// two-launch form.
+struct BnSlot {
+    double s1, s2;
+    unsigned long long tag, pad;
+};
+static std::atomic<unsigned long long> g_bn_tag{1};
+static unsigned long long bn_next_tag() { return (g_bn_tag.fetch_add(1, std::memory_order_relaxed) << 1) | 1ull; }
+
+// Called by ALL 256 threads of workgroup (c, s) with the workgroup's sums in thread 0: publish, then return true in
+// thread 0 of exactly one workgroup of the channel, with the channel totals in (s1, s2).  The S tags are checked by S
+// threads at once (S <= 256, bn_splits): one round trip, not S.
+__device__ __forceinline__ bool bn_publish(BnSlot* __restrict__ slots, unsigned long long* __restrict__ claim, int s,
+                                           int S, unsigned long long tag, double& s1, double& s2) {
+    __shared__ double shp[512];
+    __shared__ int won;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        __hip_atomic_store(&slots[s].s1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&slots[s].s2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        __hip_atomic_store(&slots[s].tag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    __syncthreads();
+    const bool here = t >= S || __hip_atomic_load(&slots[t < S ? t : 0].tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag;
+    if (!__syncthreads_and(here)) return false;
+    if (t == 0) won = __hip_atomic_exchange(claim, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag;
+    __syncthreads();
+    if (!won) return false;
+    if (t < S) {
+        shp[2 * t] = __hip_atomic_load(&slots[t].s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        shp[2 * t + 1] = __hip_atomic_load(&slots[t].s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (t != 0) return false;
+    double t1 = 0, t2 = 0;
+    for (int q = 0; q < S; ++q) { t1 += shp[2 * q]; t2 += shp[2 * q + 1]; }      // slot order: the two-launch form's bits
+    s1 = t1; s2 = t2;
+    return true;
+}
+
+struct BnFin {                // what a last arriver needs to finish a channel (nullptr slots: two-launch form)
+    BnSlot* slots;            // [C][S]
+    unsigned long long* claim;   // [C]
+    unsigned long long tag;
+    double count;
+    // forward statistics
+    const float* gamma; const float* beta; float* rmean; float* rvar; float momentum, eps;
+    float* save_mean; float* save_invstd; float* scale; float* shift;
+    // backward
+    float* dgamma; float* dbeta; float* coef; const float* mean; const float* invstd; int coef3;
+};
+
 static inline int ew_grid(int64_t n) { return (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384); }
 
 static int bn_splits(int B, int C) {
     static const int target = [] { const char* e = getenv("SCAT_BN_BLOCKS"); return e ? atoi(e) : 2048; }();
     int s = cdiv(target, C);
     if (s > B) s = B;
+    if (s > 256) s = 256;      // (one thread per slot in bn_publish)
     return s < 1 ? 1 : s;
 }
 
 // ---------------------------------------------------------------- BN forward statistics
 
+__device__ __forceinline__ void bn_finish(int c, double s1, double s2, double count, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, float* __restrict__ rmean,
+                                          float* __restrict__ rvar, float momentum, float eps,
+                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                          float* __restrict__ scale, float* __restrict__ shift);
+
 // Each block reduces channel c over images n = s, s+S, ...; the (image, pixel) pair is flattened so small
 // feature maps (7x7) still use every lane.  V = 4: 16-B loads (HW % 4 == 0).
 template <int V>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int B, int C, int HW, int S,
-                                                       FastDiv dHWv, double* __restrict__ part) {
+                                                       FastDiv dHWv, double* __restrict__ part, BnFin f) {
     const int c = blockIdx.x, s = blockIdx.y;
     const int nimg = (B - s + S - 1) / S, hwv = HW / V;
     double s1 = 0, s2 = 0;
@@ -65,7 +138,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
     __shared__ double sh[8];
     block_sum2(s1, s2, sh);
-    if (threadIdx.x == 0) {
+    if (f.slots) {
+        if (bn_publish(f.slots + (int64_t)c * S, f.claim + c, s, S, f.tag, s1, s2))
+            bn_finish(c, s1, s2, f.count, f.gamma, f.beta, f.rmean, f.rvar, f.momentum, f.eps, f.save_mean, f.save_invstd,
+                      f.scale, f.shift);
+    } else if (threadIdx.x == 0) {
         part[((int64_t)c * S + s) * 2 + 0] = s1;
         part[((int64_t)c * S + s) * 2 + 1] = s2;
     }
@@ -250,6 +327,22 @@ __device__ __forceinline__ float bn_mask(float dy, float x, float yv, bool has_y
     return dy;
 }
 
+// per-channel constants of a BatchNorm backward from the two sums (the bodies of bn_bwd_finalize_kernel / _finalize3)
+__device__ __forceinline__ void bn_bwd_finish(int c, int C, double s1, double s2, const BnFin& f) {
+    f.dbeta[c] = (float)s1;
+    f.dgamma[c] = (float)s2;
+    if (!f.coef3) {
+        f.coef[2 * c] = (float)(s1 / f.count);
+        f.coef[2 * c + 1] = (float)(s2 / f.count);
+    } else {
+        const float k1 = (float)(s1 / f.count), k2 = (float)(s2 / f.count);
+        const float ca = f.gamma[c] * f.invstd[c], cb = -ca * f.invstd[c] * k2;
+        f.coef[c] = ca;
+        f.coef[C + c] = cb;
+        f.coef[2 * C + c] = -ca * k1 - cb * f.mean[c];
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ yout,
@@ -258,7 +351,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, int B, int C, int HW,
-                                                            int S, FastDiv dHWv, double* __restrict__ part) {
+                                                            int S, FastDiv dHWv, double* __restrict__ part, BnFin f) {
     const int c = blockIdx.x, s = blockIdx.y;
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
     const int nimg = (B - s + S - 1) / S, hwv = HW / V;
@@ -289,7 +382,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
     __shared__ double shm[8];
     block_sum2(s1, s2, shm);
-    if (threadIdx.x == 0) {
+    if (f.slots) {
+        if (bn_publish(f.slots + (int64_t)c * S, f.claim + c, s, S, f.tag, s1, s2)) bn_bwd_finish(c, C, s1, s2, f);
+    } else if (threadIdx.x == 0) {
         part[((int64_t)c * S + s) * 2 + 0] = s1;
         part[((int64_t)c * S + s) * 2 + 1] = s2;
     }
@@ -380,7 +475,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_g_kernel(float* __restrict_
                                                               const float* __restrict__ shift,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, int B, int C, int HW,
-                                                              int S, FastDiv dHWv, double* __restrict__ part) {
+                                                              int S, FastDiv dHWv, double* __restrict__ part, BnFin f) {
     const int c = blockIdx.x, s = blockIdx.y;
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
     const int nimg = (B - s + S - 1) / S, hwv = HW / 4;
@@ -411,7 +506,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_g_kernel(float* __restrict_
     }
     __shared__ double shm[8];
     block_sum2(s1, s2, shm);
-    if (threadIdx.x == 0) {
+    if (f.slots) {
+        if (bn_publish(f.slots + (int64_t)c * S, f.claim + c, s, S, f.tag, s1, s2)) bn_bwd_finish(c, C, s1, s2, f);
+    } else if (threadIdx.x == 0) {
         part[((int64_t)c * S + s) * 2 + 0] = s1;
         part[((int64_t)c * S + s) * 2 + 1] = s2;
     }
@@ -566,10 +663,26 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
 
 using namespace scat;
 
+// [C][S] slots of 32 bytes (two-launch form: the first 16 of each pair of doubles) | [C] claim words | [2 C] floats
 extern "C" int64_t scat_bn_ws(int B, int C, int HW) {
     if (B <= 0 || C <= 0) return 0;
-    return (int64_t)C * bn_splits(B, C) * 2 * sizeof(double) + (int64_t)C * 2 * sizeof(float);
+    return (int64_t)C * bn_splits(B, C) * sizeof(BnSlot) + (int64_t)C * 8 + (int64_t)C * 2 * sizeof(float);
 }
+static int bn_last_arriver() {     // SCAT_BN_LASTBLOCK=0: the reduce and its finalize as two launches (A/B runs)
+    static const int m = [] { const char* e = getenv("SCAT_BN_LASTBLOCK"); return e ? atoi(e) : 1; }();
+    return m;
+}
+static BnFin bn_fin_base(void* ws, int C, int S, double count) {
+    BnFin f{};
+    if (bn_last_arriver()) {
+        f.slots = (BnSlot*)ws;
+        f.claim = (unsigned long long*)((char*)ws + (int64_t)C * S * sizeof(BnSlot));
+        f.tag = bn_next_tag();
+    }
+    f.count = count;
+    return f;
+}
+static float* bn_ws_coef(void* ws, int C, int S) { return (float*)((char*)ws + (int64_t)C * S * sizeof(BnSlot) + (int64_t)C * 8); }
 
 extern "C" int scat_bn_train_stats(const float* x, int B, int C, int HW, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, float eps,
@@ -596,15 +709,19 @@ extern "C" int scat_bn_train_stats(const float* x, int B, int C, int HW, const f
         SCAT_LAUNCH_CHECK("scat_bn_train_stats");
         return SCAT_OK;
     }
+    BnFin f = bn_fin_base(ws, C, S, (double)B * HW);
+    f.gamma = gamma; f.beta = beta; f.rmean = running_mean; f.rvar = running_var; f.momentum = momentum; f.eps = eps;
+    f.save_mean = save_mean; f.save_invstd = save_invstd; f.scale = scale; f.shift = shift;
     if ((HW & 3) == 0 && ((uintptr_t)x & 15) == 0)
         hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(C, S), dim3(256), 0, st, x, B, C, HW, S, FastDiv::make(HW / 4),
-                           (double*)ws);
+                           (double*)ws, f);
     else
         hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(C, S), dim3(256), 0, st, x, B, C, HW, S, FastDiv::make(HW),
-                           (double*)ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, C, S,
-                       (double)B * HW, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
-                       scale, shift);
+                           (double*)ws, f);
+    if (!f.slots)
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, C, S,
+                           (double)B * HW, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                           scale, shift);
     SCAT_LAUNCH_CHECK("scat_bn_train_stats");
     return SCAT_OK;
 }
@@ -691,7 +808,7 @@ extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, 
     SCAT_REQUIRE(ws && ws_bytes >= scat_bn_ws(B, C, HW), SCAT_E_WORKSPACE, "scat_bn_bwd: workspace too small");
     const int S = bn_splits(B, C);
     double* part = (double*)ws;
-    float* coef = (float*)(part + (int64_t)C * S * 2);
+    float* coef = bn_ws_coef(ws, C, S);
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)B * C * HW;
     SCAT_REQUIRE(fits_i32(total), SCAT_E_SHAPE, "scat_bn_bwd: tensor exceeds 2^31 elements");
@@ -710,14 +827,17 @@ extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, 
                                shift, save_mean, save_invstd, B, C, HW, FastDiv::make(HW), (double)B * HW, dgamma, dbeta,
                                coef);
     } else {
+        BnFin f = bn_fin_base(ws, C, S, (double)B * HW);
+        f.dgamma = dgamma; f.dbeta = dbeta; f.coef = coef; f.coef3 = 0;
         if (vec)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C, S), dim3(256), 0, st, dy, x, y_out, y_mask, relu, scale,
-                               shift, save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW / 4), part);
+                               shift, save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW / 4), part, f);
         else
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C, S), dim3(256), 0, st, dy, x, y_out, nullptr, relu, scale,
-                               shift, save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW), part);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
-                           (double)B * HW, dgamma, dbeta, coef);
+                               shift, save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW), part, f);
+        if (!f.slots)
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
+                               (double)B * HW, dgamma, dbeta, coef);
     }
     if (vec) {
         const int64_t nv = total / 4;
@@ -750,10 +870,13 @@ extern "C" int scat_bn_bwd_pre(float* dy_g, const float* dy_add, const float* x,
     const int S = bn_splits(B, C);
     double* part = (double*)ws;
     hipStream_t st = (hipStream_t)stream;
+    BnFin f = bn_fin_base(ws, C, S, (double)B * HW);
+    f.dgamma = dgamma; f.dbeta = dbeta; f.coef = coef3; f.coef3 = 1; f.gamma = gamma; f.mean = save_mean; f.invstd = save_invstd;
     hipLaunchKernelGGL(bn_bwd_reduce_g_kernel, dim3(C, S), dim3(256), 0, st, dy_g, dy_add, x, y_out, y_mask, relu, scale, shift,
-                       save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW / 4), part);
-    hipLaunchKernelGGL(bn_bwd_finalize3_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
-                       (double)B * HW, gamma, save_mean, save_invstd, dgamma, dbeta, coef3);
+                       save_mean, save_invstd, B, C, HW, S, FastDiv::make(HW / 4), part, f);
+    if (!f.slots)
+        hipLaunchKernelGGL(bn_bwd_finalize3_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
+                           (double)B * HW, gamma, save_mean, save_invstd, dgamma, dbeta, coef3);
     SCAT_LAUNCH_CHECK("scat_bn_bwd_pre");
     return SCAT_OK;
 }

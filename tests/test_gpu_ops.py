@@ -1140,3 +1140,61 @@ def test_gemm_group(ops):
         for (dy, x), o, r in zip(pairs, outs, refs):
             assert rel_err(o, r) < 2e-5
             assert rel_err(o, ops.linear_wgrad(dy, x)) < 5e-6
+
+
+@pytest.mark.parametrize("B,C,H", [(96, 32, 28), (7, 64, 14), (96, 128, 7), (3, 16, 5), (33, 200, 9)])
+def test_batchnorm_last_arriver_finalize(ops, B, C, H):
+    """The per-channel reduce of the BatchNorm statistics / backward sums finishes in the workgroup that arrives last
+    (csrc/norm.hip bn_publish) instead of in a second launch: same bits as the two-launch form (SCAT_BN_LASTBLOCK=0, a
+    child process), every call finishes every channel EXACTLY once (the running statistics follow the recurrence over 40
+    repeated calls), forward statistics, backward sums and the folded-backward constants."""
+    import subprocess
+    import sys
+    x = t(201, "x", (B, C, H, H)) * 1.7 + 0.4
+    dy = t(202, "dy", (B, C, H, H))
+    gamma = torch.from_numpy(synth.uniform(203, "g", (C,), 0.5, 1.5))
+    beta = torch.from_numpy(synth.uniform(204, "b", (C,), -0.3, 0.3))
+    xg, dyg, gg, bg = g(x), g(dy), g(gamma), g(beta)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    outs = []
+    for it in range(40):
+        mean, invstd, scale, shift = ops.bn_train_stats(xg, gg, bg, rm, rv)
+        outs.append(torch.stack((mean, invstd, scale, shift)).clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    m64 = x.double().mean(dim=(0, 2, 3))
+    v64 = x.double().var(dim=(0, 2, 3), unbiased=True)
+    k = 1.0 - 0.9 ** 40
+    assert rel_err(rm, k * m64) < 1e-5 and rel_err(rv, 0.9 ** 40 + k * v64) < 1e-5      # 40 updates, not 39 or 41
+    assert rel_err(mean, m64) < 1e-6
+    dxs = []
+    for it in range(10):
+        dxg, dgg, dbg = ops.bn_bwd(dyg.clone(), xg, None, True, scale, shift, mean, invstd, gg)
+        dxs.append(torch.cat((dxg.flatten()[:4096], dgg, dbg)).clone())
+    assert all(torch.equal(dxs[0], o) for o in dxs[1:])
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5))
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(yr, (xr, gr, br), dy.double())
+    assert rel_err(dxg, dx_ref) < 2e-5 and rel_err(dgg, dg_ref) < 2e-5 and rel_err(dbg, db_ref) < 2e-5
+    if (H * H) % 4 == 0:
+        gbuf = dyg.clone()
+        coef3, dg3, db3 = ops.bn_bwd_pre(gbuf, xg, True, scale, shift, mean, invstd, gg)
+        formed = coef3[0].view(1, -1, 1, 1) * gbuf + coef3[1].view(1, -1, 1, 1) * xg + coef3[2].view(1, -1, 1, 1)
+        assert rel_err(formed, dx_ref) < 2e-5 and rel_err(dg3, dg_ref) < 2e-5
+    # the two-launch form gives the same bits
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_ops as T\nfrom scat_amd import ops, synth\n"
+            "x = T.g(T.t(201, 'x', (%d, %d, %d, %d)) * 1.7 + 0.4)\n"
+            "gm = T.g(torch.from_numpy(synth.uniform(203, 'g', (%d,), 0.5, 1.5))); bt = T.g(torch.from_numpy(synth.uniform(204, 'b', (%d,), -0.3, 0.3)))\n"
+            "rm, rv = torch.zeros(%d, device='cuda'), torch.ones(%d, device='cuda')\n"
+            "o = ops.bn_train_stats(x, gm, bt, rm, rv)\n"
+            "torch.save(torch.stack(o).cpu(), sys.argv[1])\n") % (root, os.path.join(root, "tests"), B, C, H, H, C, C, C, C)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "two.pt")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, SCAT_BN_LASTBLOCK="0"), capture_output=True,
+                           text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        two = torch.load(f)
+    assert torch.equal(outs[0].cpu(), two)
