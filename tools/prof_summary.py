@@ -4,7 +4,9 @@ import csv, re, sys
 path = sys.argv[1]
 rows = list(csv.DictReader(open(path)))
 if len(sys.argv) > 2 and sys.argv[2] == "auto":      # one loss kernel per train step
-    steps = float(next(r["Calls"] for r in rows if "loss_kernel" in r["Name"]))
+    # (the HRNet bench step has no loss kernel: one preprocess kernel per step there)
+    steps = float(next((r["Calls"] for r in rows if "loss_kernel" in r["Name"]), None) or
+                  next(r["Calls"] for r in rows if "preprocess_kernel" in r["Name"]))
 else:
     steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 def short(n):
