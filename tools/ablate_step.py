@@ -25,6 +25,9 @@ CLASSES = {
     "stem": ["scat_conv7x7_s2_fwd_split", "scat_conv7x7_s2_wgrad_split", "scat_maxpool3x3s2_fwd", "scat_maxpool3x3s2_bwd"],
     "bn_fwd": ["scat_bn_apply", "scat_bn_train_stats", "scat_bn_train_stats_partials"],
     "bn_bwd": ["scat_bn_bwd", "scat_bn_bwd_pre"],
+    "epi_fin": ["scat_bn_train_stats_partials", "scat_bn_train_stats_partials_shifted"],   # the finalize launches only
+    "bn_apply": ["scat_bn_apply"],
+    "bn_bwd_pre": ["scat_bn_bwd_pre"],
     "tokens": ["scat_gemm", "scat_attention_fwd", "scat_attention_bwd", "scat_layernorm_fwd", "scat_layernorm_bwd",
                "scat_gelu_fwd", "scat_gelu_bwd", "scat_colsum"],
     "adam_wprep": ["scat_adam", "scat_wprep_run"],
