@@ -4,6 +4,7 @@
 // Reference: nn.BatchNorm2d at models/resnet.py:68-73,108,131; nn.LayerNorm at
 // models/vision_transformer.py:20-26.
 #include <atomic>
+#include <chrono>
 
 #include "common.h"
 
@@ -49,8 +50,18 @@ struct BnSlot {
     double s1, s2;
     unsigned long long tag, pad;
 };
+// Launch tags: a bijective 64-bit mix (splitmix64's finaliser) of a salted counter — unique per launch of this process, and
+// a recycled workspace holds one by accident with probability 2^-64 per slot (a plain counter would collide with any
+// small integer a previous owner of the memory left there).
 static std::atomic<unsigned long long> g_bn_tag{1};
-static unsigned long long bn_next_tag() { return (g_bn_tag.fetch_add(1, std::memory_order_relaxed) << 1) | 1ull; }
+static unsigned long long bn_next_tag() {
+    static const unsigned long long salt =
+        (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull;
+    unsigned long long z = g_bn_tag.fetch_add(1, std::memory_order_relaxed) + salt;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
 
 // Called by ALL 256 threads of workgroup (c, s) with the workgroup's sums in thread 0: publish, then return true in
 // thread 0 of exactly one workgroup of the channel, with the channel totals in (s1, s2).  The S tags are checked by S

@@ -31,7 +31,8 @@ def test_header_declares_the_path():
         if rt is ctypes.c_int and name not in ("scat_version", "scat_check_device", "scat_get_math_mode",
                                                 "scat_set_math_mode",
                                                 # host-side state of the NEXT launch of this thread, no device work
-                                                "scat_epilogue_stats_arm", "scat_epilogue_stats_groups", "scat_streamk_arm"):
+                                                "scat_epilogue_stats_arm", "scat_epilogue_stats_arm_shift", "scat_epilogue_stats_groups",
+                                                "scat_streamk_arm"):
             assert args[-1][1] == "stream", name
     # every prototype cites the reference file it replaces somewhere in the header
     src = open(os.path.join(ROOT, "include", "scat_hip.h")).read()
