@@ -117,8 +117,16 @@ class GradBuckets:
         self.check = _dp_check()
         self._avg_ok = False
         if self.collective:
+            if dev.type == "cuda":
+                # hardware queues (scat_amd.streams): normally planned by init_distributed() before the process group came
+                # up; a group the caller created itself is met here, too late for the collective stream but not for ours
+                from . import streams
+                streams.bind(dev, ["wgrad", "tokens"])
             self._sync_replicas(model)
             self._avg_ok = self._probe_avg()
+            if dev.type == "cuda":
+                streams.bind(dev, ["comm"])
+                streams.alias(dev, "opt", "comm")
         backbone = getattr(model, "main_encoder", None)
         if backbone is not None:
             backbone._grad_sink = self
@@ -170,7 +178,8 @@ class GradBuckets:
         made to wait for each other, so their overlap is untouched)."""
         cur = torch.cuda.current_stream(device)
         if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=device)
+            from . import streams
+            self._comm_stream = streams.get(device, "comm")
         c = self._comm_stream
         c.wait_stream(cur)
         for s in _PRODUCERS:
@@ -383,6 +392,9 @@ def init_distributed():
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local)
+        if torch.cuda.is_available():
+            from . import streams     # hardware queues: the train step's streams are bound before RCCL's (streams.py)
+            streams.plan_for_collectives(torch.device("cuda", local))
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local, world
 

@@ -77,19 +77,17 @@ def _upload_indices(idx, device):
 OVERLAP_TOKENS = os.environ.get("SCAT_OVERLAP_TOKENS", "1") != "0"   # token path next to layer3/layer4 (own stream)
 TOKENS_FIRST_IN_BACKWARD = os.environ.get("SCAT_TOKENS_FIRST", "1") != "0"   # (0: the round-2 node order, for A/B runs)
 TOKEN_PRIO = os.environ.get("SCAT_TOKEN_PRIO", "0") != "0"   # token stream with high priority (A/B switch)
-_TOKEN_STREAMS = {}
 # The token-path parameters get their gradients from nodes that ran on the token stream while their AccumulateGrad
 # nodes belong to the caller's stream: autograd orders the two (that is the design) and says so once per process.
 warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
 
 
 def _token_stream(device):
-    key = str(device)
-    if key not in _TOKEN_STREAMS:
-        _TOKEN_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if TOKEN_PRIO else 0)
-        from ..dp import register_producer
-        register_producer(_TOKEN_STREAMS[key])
-    return _TOKEN_STREAMS[key]
+    from .. import streams
+    if TOKEN_PRIO and "tokens" not in streams.bound(device):
+        streams.get(device, "wgrad")
+        streams.bind(device, ["tokens"], priority=-1)
+    return streams.get(device, "tokens")
 
 
 def _backbone_with_tokens(backbone, main_input, token_path):

@@ -74,16 +74,11 @@ _DEFER_NBT = [False]     # set by HRNet.forward: the blocks leave their num_batc
 EPI_STATS = os.environ.get("SCAT_HRNET_EPI", "0") != "0"
 FUSED_BASIC = os.environ.get("SCAT_HRNET_FUSED", "1") != "0"   # 0: the per-layer autograd path, for A/B runs
 PARALLEL_BRANCHES = os.environ.get("SCAT_HRNET_PAR", "1") != "0"   # one stream per resolution branch of a stage
-_BRANCH_STREAMS = {}
 
 
 def _branch_stream(device, i):
-    key = (str(device), i)
-    if key not in _BRANCH_STREAMS:
-        _BRANCH_STREAMS[key] = torch.cuda.Stream(device=device)
-        from ..dp import register_producer
-        register_producer(_BRANCH_STREAMS[key])
-    return _BRANCH_STREAMS[key]
+    from .. import streams
+    return streams.get(device, "branch%d" % i)
 
 
 class Bottleneck(nn.Module):

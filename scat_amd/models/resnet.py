@@ -80,7 +80,6 @@ class _BNState:
             self.mean = self.invstd = None
 
 
-_SIDE = {}
 BNB1 = os.environ.get("SCAT_BNB1", "0") != "0"   # same for bn1 -> conv1: measured slower (its passes hide under the side stream), off
 BNB1_MIN_H = int(os.environ.get("SCAT_BNB1_MIN_H", "0"))
 BNB_MIN_H = int(os.environ.get("SCAT_BNB_MIN_H", "28"))   # fold bn3 only where it pays: 56x56 and 28x28 planes (tools/bnb_bench.py: at 14x14 the dual-source kernels cost more than the pass they save)
@@ -91,15 +90,12 @@ SIDE_WGRAD = os.environ.get("SCAT_SIDE_WGRAD", "1") != "0"   # bench.py clears i
 
 
 def _side_stream(device, who="backbone"):
-    """One side stream per device (and user) for the weight-gradient contractions (SCAT_SIDE_WGRAD=0 disables)."""
+    """The side stream of the weight-gradient contractions (SCAT_SIDE_WGRAD=0 disables): the backbone's, or the token
+    path's (who="tokens").  Created through scat_amd.streams so that it gets a hardware queue of its own."""
     if not SIDE_WGRAD:
         return None
-    key = (str(device), who)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
-        from ..dp import register_producer
-        register_producer(_SIDE[key])      # gradient kernels run here: collectives are ordered after it explicitly
-    return _SIDE[key]
+    from .. import streams
+    return streams.get(device, "wgrad" if who == "backbone" else "tokens_wgrad")
 
 
 STAT_REF = os.environ.get("SCAT_STAT_REF", "1") != "0"   # epilogue BatchNorm sums about the previous step's batch mean

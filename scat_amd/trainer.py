@@ -49,14 +49,11 @@ def pose_length_term(pl_term):
 
 
 EARLY_ADAM = os.environ.get("SCAT_EARLY_ADAM", "1") != "0"
-_AUX = {}
 
 
 def _aux_stream(device):
-    key = str(device)
-    if key not in _AUX:
-        _AUX[key] = torch.cuda.Stream(device=device)
-    return _AUX[key]
+    from . import streams
+    return streams.get(device, "aux")
 
 
 class FusedAdam:
@@ -94,7 +91,8 @@ class FusedAdam:
             return
         main = torch.cuda.current_stream()
         if self._opt_stream is None:
-            self._opt_stream = torch.cuda.Stream(device=self.b.flat_param.device)
+            from . import streams      # (with collectives: the stream they are ordered after — it waits for them anyway)
+            self._opt_stream = streams.get(self.b.flat_param.device, "opt")
         opt = self._opt_stream
         opt.wait_stream(main)
         with torch.cuda.stream(opt):

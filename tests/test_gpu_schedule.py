@@ -20,3 +20,35 @@ def test_switches_do_not_change_the_numbers():
     assert abs(a[0] - b[0]) / abs(b[0]) < 2e-6, (a, b)
     for u, v in zip(a[1:], b[1:]):
         assert abs(u - v) / abs(v) < 5e-2, (a, b)
+
+
+@pytest.mark.timeout(600)
+def test_step_streams_do_not_share_hardware_queues():
+    """scat_amd.streams picks every role's stream by measuring which pool streams share a hardware queue (HIP multiplexes
+    all streams of a process onto four): after a train step the backbone's weight-gradient stream and the token stream run
+    beside the main stream and beside each other, and the probe itself tells one stream from two on one queue."""
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from scat_amd import streams
+
+    dev = torch.device("cuda", 0)
+    net = bench.make_net("resnet50", 1, dev)
+    step = bench.Step("resnet50", net, dev)
+    u8, lab = bench.build_inputs(8, 5, dev)
+    for _ in range(2):
+        step(u8, lab)
+    torch.cuda.synchronize()
+    roles = streams.bound(dev)
+    assert {"wgrad", "tokens"} <= set(roles), list(roles)
+    pairs = {frozenset((a, b)) for a, b, _ in streams.sharing(dev)}
+    for bad in (("main", "wgrad"), ("main", "tokens"), ("wgrad", "tokens"), ("main", "tokens_wgrad"), ("main", "opt")):
+        assert frozenset(bad) not in pairs, pairs
+    main = torch.cuda.default_stream(dev)
+    assert streams._shares(main, main)
+    # the probe finds the queue-mates of a stream among the pool: with four hardware queues, 8 more streams cannot all
+    # run beside main, the weight-gradient stream and the token stream
+    more = [torch.cuda.Stream(device=dev) for _ in range(8)]
+    heavy = [main, roles["wgrad"], roles["tokens"]]
+    assert any(any(streams._shares(s, h) for h in heavy) for s in more)
