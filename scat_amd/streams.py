@@ -23,7 +23,11 @@ one after the other: ``_shares``).  What may share is what is sequential anyway:
 """
 from __future__ import annotations
 
+import os
+
 import torch
+
+PROBE = os.environ.get("SCAT_STREAMS_PROBE", "1") != "0"   # 0: take pool streams as they come (A/B runs)
 
 _BOUND = {}          # device index -> {role: stream}
 ORDER = ("wgrad", "tokens", "comm", "tokens_wgrad", "aux", "opt")
@@ -80,7 +84,7 @@ def _pick(device, avoid):
     s = None
     for _ in range(32):
         s = torch.cuda.Stream(device=device)
-        if not any(_shares(s, a) for a in avoid):
+        if not PROBE or not any(_shares(s, a) for a in avoid):
             return s
     return s
 
