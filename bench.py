@@ -391,6 +391,11 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config == "resnet50":
         cpu = cpu_baseline()
 
+    # which side streams of the step share a hardware queue on this rank (scat_amd/streams.py; ~20 ms of spin kernels,
+    # after everything that is timed): evidence that the queue plan held where the step actually ran
+    from scat_amd import streams
+    queue_mates = ["+".join((x, y)) + (" (one stream)" if why == "same stream" else "") for x, y, why in streams.sharing(dev)]
+
     if rank == 0:
         imgs = a.batch * world * a.steps
         step_tf = GF_TRAIN_PER_IMG[a.config] * a.batch / (dt / a.steps) / 1e3
@@ -416,7 +421,8 @@ def main():
                        "products": ("fp32 operands as 3 bf16 terms, 6 bf16 MFMA terms per product, fp32 accumulate "
                                     "(error <= 2^-25 per product; DESIGN.md 3.0)" if lib().scat_get_math_mode() == 1
                                     else "fp32 MFMA"),
-                       "whole_step_tflops_per_gpu": round(step_tf, 2), "pcie_inclusive": pcie},
+                       "whole_step_tflops_per_gpu": round(step_tf, 2), "pcie_inclusive": pcie,
+                       "hw_queue_mates": queue_mates},
             "roofline": roof, "roofline_hbm": roof_hbm, "cpu_baseline": cpu,
         }
         print(json.dumps(out), file=json_out, flush=True)
