@@ -73,6 +73,7 @@ _DEFER_NBT = [False]     # set by HRNet.forward: the blocks leave their num_batc
 # statistics passes already hidden on the branch streams: 70.0 vs 69.0 ms / step), so off here; ResNet-50: +1.8 %
 EPI_STATS = os.environ.get("SCAT_HRNET_EPI", "0") != "0"
 FUSED_BASIC = os.environ.get("SCAT_HRNET_FUSED", "1") != "0"   # 0: the per-layer autograd path, for A/B runs
+FUSED_BOTTLENECK = os.environ.get("SCAT_HRNET_FUSED_L1", "1") != "0"   # layer1's Bottlenecks on ResNet's block executor
 PARALLEL_BRANCHES = os.environ.get("SCAT_HRNET_PAR", "1") != "0"   # one stream per resolution branch of a stage
 
 
@@ -97,6 +98,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if FUSED_BOTTLENECK and x.is_cuda:
+            # layer1's four Bottlenecks are ResNet-50's layer1 (models/resnet.py:78-98, 64 / 256 channels at 56 x 56): the
+            # same fused block executor — BatchNorm sums in the convolution epilogues, bn1 / bn2 + ReLU folded into the next
+            # convolution's operand load, bn3 + shortcut + ReLU one pass with a 1-bit sign mask, folded bn3 backward
+            return _rn._BlockFn.apply(x, self, *self.parameters())
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
@@ -234,17 +240,17 @@ class HRNet(nn.Module):
         # start of forward instead of 2 x 293 small ones spread over the step
         object.__setattr__(self, "_wprep", ops.WeightPrep())
         for m in self.modules():
-            if isinstance(m, (snn.Conv2d, BasicBlock)):
+            if isinstance(m, (snn.Conv2d, BasicBlock, Bottleneck)):
                 object.__setattr__(m, "_wprep", self._wprep)
 
     def forward(self, x):
         # the 208 fused blocks bump their num_batches_tracked counters with ONE multi-tensor add at the end of the
         # forward instead of one tiny launch per block
-        _DEFER_NBT[0] = True
+        _DEFER_NBT[0] = _rn._DEFER[0] = True
         try:
             return self._forward(x)
         finally:
-            _DEFER_NBT[0] = False
+            _DEFER_NBT[0] = _rn._DEFER[0] = False
             if _rn._NBT:
                 torch._foreach_add_(_rn._NBT, 1)
                 _rn._NBT.clear()

@@ -54,6 +54,7 @@ def _bn_buffers(bn):
 
 
 _NBT = []   # num_batches_tracked buffers touched by the running forward: bumped by ONE multi-tensor add at its end
+_DEFER = [False]   # set by a network whose forward bumps them itself at its end (HRNet): stand-alone blocks leave _NBT alone
 
 
 class _BNState:
@@ -301,9 +302,11 @@ class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, blk, *params):
         x = x if x.is_contiguous() else x.contiguous()
-        _NBT.clear()
-        rec = _block_forward(blk, x, blk.training, None)
-        if _NBT:
+        if not _DEFER[0]:
+            _NBT.clear()
+        # (a network that prepares all its convolution weights with one launch hands its ops.WeightPrep to its blocks: HRNet)
+        rec = _block_forward(blk, x, blk.training, getattr(blk, "_wprep", None))
+        if _NBT and not _DEFER[0]:
             torch._foreach_add_(_NBT, 1)
             _NBT.clear()
         out = rec[10]
@@ -320,7 +323,7 @@ class _BlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         if ctx.rec is None:
             raise RuntimeError("scat_amd: Bottleneck backward needs a training-mode forward (BN batch statistics)")
-        bc = _Bwd(None, dout.device, None)
+        bc = _Bwd(None, dout.device, getattr(ctx.rec[0], "_wprep", None))
         dcur = dout.contiguous().clone()               # masked in place below; the caller's tensor stays intact
         dx = _block_backward(bc, ctx.rec, dcur)
         bc.join()
