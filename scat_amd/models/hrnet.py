@@ -65,6 +65,53 @@ class _BasicBlockFn(torch.autograd.Function):
         return dx, None, dw1, dg1, db1, dw2, dg2, db2
 
 
+class _CbrFn(torch.autograd.Function):
+    """conv -> BatchNorm -> ReLU (models/hrnet.py: the stem, the transitions, the inner units of the strided fuse chains) as
+    ONE autograd node instead of three: the BatchNorm's sums come from the convolution's epilogue where its kernel has one
+    (else one pass), normalise + ReLU is one pass, nothing but the raw convolution output is kept for the backward (the
+    ReLU sign is recomputed from it inside the BatchNorm backward) — no separate ReLU forward / backward passes."""
+
+    @staticmethod
+    def forward(ctx, x, conv, bn, w, gamma, beta):
+        training = bn.training
+        x = x if x.is_contiguous() else x.contiguous()
+        wp = getattr(conv, "_wprep", None)
+        st, pd = conv.stride[0], conv.padding[0]
+        c = ops.conv2d_fwd(x, w, st, pd, wp=wp, stats=training and EPI_STATS_CBR,
+                           stats_shift=_rn._ref(bn) if training else None)
+        s = _rn._BNState(c, bn, training)
+        if _rn._NBT and not _DEFER_NBT[0]:
+            torch._foreach_add_(_rn._NBT, 1)
+            _rn._NBT.clear()
+        out = ops.bn_apply(c, s.scale, s.shift, None, True)
+        if training and any(ctx.needs_input_grad):
+            ctx.conv, ctx.bn, ctx.s = conv, bn, s
+            ctx.save_for_backward(x, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, c = ctx.saved_tensors
+        conv, bn, s = ctx.conv, ctx.bn, ctx.s
+        st, pd = conv.stride[0], conv.padding[0]
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        dc, dg, db = ops.bn_bwd(dout, c, None, True, s.scale, s.shift, s.mean, s.invstd, bn.weight)
+        dw = ops.conv2d_wgrad(dc, x, tuple(conv.weight.shape), st, pd) if ctx.needs_input_grad[3] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_dgrad_w(dc, conv.weight, tuple(x.shape), st, pd, wp=getattr(conv, "_wprep", None))
+        return dx, None, None, dw, dg, db
+
+
+class _CBR(nn.Sequential):
+    """nn.Sequential(Conv2d, BatchNorm2d, ReLU) with the reference's state_dict keys, executed as one node"""
+
+    def forward(self, x):
+        if FUSED_CBR and x.is_cuda and self[0].bias is None:
+            return _CbrFn.apply(x, self[0], self[1], self[0].weight, self[1].weight, self[1].bias)
+        return super().forward(x)
+
+
 import os
 
 _DEFER_NBT = [False]     # set by HRNet.forward: the blocks leave their num_batches_tracked bumps to its end
@@ -73,6 +120,8 @@ _DEFER_NBT = [False]     # set by HRNet.forward: the blocks leave their num_batc
 # statistics passes already hidden on the branch streams: 70.0 vs 69.0 ms / step), so off here; ResNet-50: +1.8 %
 EPI_STATS = os.environ.get("SCAT_HRNET_EPI", "0") != "0"
 FUSED_BASIC = os.environ.get("SCAT_HRNET_FUSED", "1") != "0"   # 0: the per-layer autograd path, for A/B runs
+FUSED_CBR = os.environ.get("SCAT_HRNET_FUSED_CBR", "1") != "0"   # conv + BatchNorm + ReLU units as one node each
+EPI_STATS_CBR = os.environ.get("SCAT_HRNET_CBR_EPI", "1") != "0"   # ... with the BatchNorm sums from the convolution epilogue
 FUSED_BOTTLENECK = os.environ.get("SCAT_HRNET_FUSED_L1", "1") != "0"   # layer1's Bottlenecks on ResNet's block executor
 PARALLEL_BRANCHES = os.environ.get("SCAT_HRNET_PAR", "1") != "0"   # one stream per resolution branch of a stage
 
@@ -156,7 +205,7 @@ class StageModule(nn.Module):
                 else:
                     chain = []
                     for _ in range(i - j - 1):
-                        chain.append(nn.Sequential(
+                        chain.append(_CBR(
                             snn.Conv2d(c * (2 ** j), c * (2 ** j), kernel_size=(3, 3), stride=(2, 2), padding=(1, 1),
                                        bias=False),
                             snn.BatchNorm2d(c * (2 ** j), eps=1e-05, momentum=0.1),
@@ -224,9 +273,8 @@ class HRNet(nn.Module):
                                     Bottleneck(256, 64), Bottleneck(256, 64))
 
         def cbr(cin, cout, stride):
-            return nn.Sequential(snn.Conv2d(cin, cout, kernel_size=(3, 3), stride=(stride, stride), padding=(1, 1),
-                                            bias=False),
-                                 snn.BatchNorm2d(cout, eps=1e-05, momentum=m), snn.ReLU(inplace=True))
+            return _CBR(snn.Conv2d(cin, cout, kernel_size=(3, 3), stride=(stride, stride), padding=(1, 1), bias=False),
+                        snn.BatchNorm2d(cout, eps=1e-05, momentum=m), snn.ReLU(inplace=True))
 
         self.transition1 = nn.ModuleList([cbr(256, c, 1), nn.Sequential(cbr(256, c * 2, 2))])
         self.stage2 = nn.Sequential(StageModule(2, 2, c, m))
@@ -257,8 +305,12 @@ class HRNet(nn.Module):
 
     def _forward(self, x):
         self._wprep.run(self.training)
-        x = self.relu(self.bn1(self.conv1(x)))
-        x = self.relu(self.bn2(self.conv2(x)))
+        if FUSED_CBR and x.is_cuda:
+            x = _CbrFn.apply(x, self.conv1, self.bn1, self.conv1.weight, self.bn1.weight, self.bn1.bias)
+            x = _CbrFn.apply(x, self.conv2, self.bn2, self.conv2.weight, self.bn2.weight, self.bn2.bias)
+        else:
+            x = self.relu(self.bn1(self.conv1(x)))
+            x = self.relu(self.bn2(self.conv2(x)))
         x = self.layer1(x)
         x = [trans(x) for trans in self.transition1]
         x = self.stage2(x)
