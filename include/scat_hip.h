@@ -310,6 +310,12 @@ int scat_preprocess_u8(const uint8_t* src, float* dst, int B, int SH, int SW, in
  * (hand_net.py:203 feat.mean(dim=1); vision_performer.py:108) */
 int scat_upsample_nearest_fwd(const float* x, float* y, int B, int C, int H, int W, int factor, void* stream);
 int scat_upsample_nearest_bwd(const float* dy, float* dx, int B, int C, int H, int W, int factor, void* stream);
+/* one output of an HRNet exchange unit (models/hrnet.py:117-144: fuse_layers[i] summed, then ReLU) in one pass:
+ * out[B,C,H,W] = relu?( sum_{j<n} term_j ),  term_j = sc_j[c] * in_j[b, c, y >> k_j, x >> k_j] + sh_j[c]  (sc_j = sh_j =
+ * NULL: in_j as it is), in_j of shape [B, C, H >> k_j, W >> k_j]; terms are added in the order given.  n <= 4. */
+int scat_fuse_sum(const float* in0, const float* in1, const float* in2, const float* in3, const float* sc0, const float* sc1,
+                  const float* sc2, const float* sc3, const float* sh0, const float* sh1, const float* sh2, const float* sh3,
+                  int k0, int k1, int k2, int k3, int n, float* out, int B, int C, int H, int W, int relu, void* stream);
 int scat_token_mean_fwd(const float* x, float* y, int B, int T, int D, void* stream);
 int scat_token_mean_bwd(const float* dy, float* dx, int B, int T, int D, void* stream);
 

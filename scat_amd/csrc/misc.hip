@@ -549,6 +549,65 @@ extern "C" int scat_preprocess_u8(const uint8_t* src, float* dst, int B, int SH,
     return SCAT_OK;
 }
 
+// ---------------------------------------------------------------- exchange-unit sum (hrnet.py:117-144)
+//
+// One output of a StageModule's exchange is relu(sum_j f_ij(x_j)): the branch's own map, 1x1 convolutions of the
+// lower-resolution branches (BatchNorm, nearest upsample by 2^k) and strided 3x3 chains of the higher-resolution ones
+// (BatchNorm).  One pass: every term is read once at ITS resolution, normalised by its BatchNorm's (scale, shift) if it has
+// one, and added in the order given (the reference's order of additions); the ReLU rides along.  Replaces, per term, a
+// BatchNorm apply pass, an upsample pass and an add pass, and the final ReLU pass.
+struct FuseSumDesc {
+    const float* in[4];
+    const float* sc[4];       // nullptr: the term is taken as it is
+    const float* sh[4];
+    int k[4];                 // log2 of the nearest-upsample factor of the term
+    int n, C, H, W, relu;
+};
+
+template <bool V4>
+__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseSumDesc d, float* __restrict__ out, int64_t total) {
+    constexpr int V = V4 ? 4 : 1;
+    const int Wv = d.W / V;
+    GRID_STRIDE(e, total) {
+        const int xv = (int)(e % Wv);
+        const int64_t r = e / Wv;
+        const int y = (int)(r % d.H);
+        const int64_t nc = r / d.H;
+        const int c = (int)(nc % d.C);
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= d.n) break;
+            const int k = d.k[j];
+            const float sc = d.sc[j] ? d.sc[j][c] : 1.f, sh = d.sc[j] ? d.sh[j][c] : 0.f;
+            float v[V];
+            if (k == 0) {
+                if constexpr (V4) {
+                    const float4 t = *reinterpret_cast<const float4*>(d.in[j] + e * 4);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+                    v[0] = d.in[j][e];
+                }
+            } else {
+                const float* p = d.in[j] + (nc * (d.H >> k) + (y >> k)) * (int64_t)(d.W >> k);
+#pragma unroll
+                for (int i = 0; i < V; ++i) v[i] = p[(xv * V + i) >> k];
+            }
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float t = d.sc[j] ? fmaf(v[i], sc, sh) : v[i];
+                acc[i] = j == 0 ? t : acc[i] + t;
+            }
+        }
+        if (d.relu) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] = fmaxf(acc[i], 0.f);
+        }
+        if constexpr (V4) *reinterpret_cast<float4*>(out + e * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else out[e] = acc[0];
+    }
+}
+
 extern "C" int scat_upsample_nearest_fwd(const float* x, float* y, int B, int C, int H, int W, int factor,
                                          void* stream) {
     SCAT_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && factor >= 1, SCAT_E_ARG,
@@ -565,6 +624,31 @@ extern "C" int scat_upsample_nearest_bwd(const float* dy, float* dx, int B, int 
     int64_t n = (int64_t)B * C * H * W;
     hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, H, W, factor);
     SCAT_LAUNCH_CHECK("scat_upsample_nearest_bwd");
+    return SCAT_OK;
+}
+extern "C" int scat_fuse_sum(const float* in0, const float* in1, const float* in2, const float* in3, const float* sc0,
+                             const float* sc1, const float* sc2, const float* sc3, const float* sh0, const float* sh1,
+                             const float* sh2, const float* sh3, int k0, int k1, int k2, int k3, int n, float* out, int B,
+                             int C, int H, int W, int relu, void* stream) {
+    SCAT_REQUIRE(out && n >= 1 && n <= 4 && B > 0 && C > 0 && H > 0 && W > 0, SCAT_E_ARG, "scat_fuse_sum: bad argument");
+    FuseSumDesc d{};
+    const float* in[4] = {in0, in1, in2, in3};
+    const float* sc[4] = {sc0, sc1, sc2, sc3};
+    const float* sh[4] = {sh0, sh1, sh2, sh3};
+    const int k[4] = {k0, k1, k2, k3};
+    bool v4 = W % 4 == 0 && ((uintptr_t)out & 15) == 0;
+    for (int j = 0; j < n; ++j) {
+        SCAT_REQUIRE(in[j] && (sc[j] == nullptr) == (sh[j] == nullptr), SCAT_E_ARG, "scat_fuse_sum: null term / scale without shift");
+        SCAT_REQUIRE(k[j] >= 0 && k[j] < 8 && H % (1 << k[j]) == 0 && W % (1 << k[j]) == 0, SCAT_E_SHAPE,
+                     "scat_fuse_sum: the map is not a multiple of a term's upsample factor");
+        d.in[j] = in[j]; d.sc[j] = sc[j]; d.sh[j] = sh[j]; d.k[j] = k[j];
+        if (k[j] == 0 && ((uintptr_t)in[j] & 15)) v4 = false;
+    }
+    d.n = n; d.C = C; d.H = H; d.W = W; d.relu = relu;
+    const int64_t total = (int64_t)B * C * H * W / (v4 ? 4 : 1);
+    if (v4) hipLaunchKernelGGL(fuse_sum_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, d, out, total);
+    else hipLaunchKernelGGL(fuse_sum_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, d, out, total);
+    SCAT_LAUNCH_CHECK("scat_fuse_sum");
     return SCAT_OK;
 }
 extern "C" int scat_token_mean_fwd(const float* x, float* y, int B, int T, int D, void* stream) {

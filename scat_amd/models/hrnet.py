@@ -103,6 +103,60 @@ class _CbrFn(torch.autograd.Function):
         return dx, None, None, dw, dg, db
 
 
+class _FuseSumFn(torch.autograd.Function):
+    """One output of an exchange unit (models/hrnet.py:117-144): relu(sum_j term_j) as one node and ONE forward pass.  A
+    term is the branch's own map, or the raw output of the last convolution of fuse_layers[i][j] together with that
+    layer's BatchNorm (and its upsample factor 2^k): the BatchNorm's statistics are taken here, its normalise, the
+    upsample, the additions (in the reference's order) and the ReLU are scat_fuse_sum.  Backward: the masked gradient is
+    the gradient of every same-resolution term, its 2^k x 2^k block sums that of an upsampled one; each BatchNorm's
+    backward follows."""
+
+    @staticmethod
+    def forward(ctx, spec, *flat):
+        # spec: tuple of (bn module | None, k) per term, in order; flat: the terms' tensors, then (gamma, beta) of every
+        # term that has a BatchNorm
+        n = len(spec)
+        tens = [t if t.is_contiguous() else t.contiguous() for t in flat[:n]]
+        training = any(bn is not None and bn.training for bn, _ in spec)
+        states, terms = [], []
+        for (bn, k), t in zip(spec, tens):
+            if bn is None:
+                states.append(None)
+                terms.append((t, None, None, k))
+            else:
+                st = _rn._BNState(t, bn, bn.training)
+                states.append(st)
+                terms.append((t, st.scale, st.shift, k))
+        if _rn._NBT and not _DEFER_NBT[0]:
+            torch._foreach_add_(_rn._NBT, 1)
+            _rn._NBT.clear()
+        out = ops.fuse_sum(terms, relu=True)
+        if training and any(ctx.needs_input_grad):
+            ctx.spec, ctx.states = spec, states
+            ctx.save_for_backward(out, *tens)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, *tens = ctx.saved_tensors
+        spec, states = ctx.spec, ctx.states
+        n = len(spec)
+        gm = ops.relu_bwd(dout if dout.is_contiguous() else dout.contiguous(), out)
+        grads, pgrads = [], []
+        down = {0: gm}
+        for (bn, k), st, t in zip(spec, states, tens):
+            if k not in down:
+                down[k] = ops.upsample_nearest_bwd(gm, 1 << k)
+            g = down[k]
+            if bn is None:
+                grads.append(g)
+            else:
+                dc, dg, db = ops.bn_bwd(g, t, None, False, st.scale, st.shift, st.mean, st.invstd, bn.weight)
+                grads.append(dc)
+                pgrads += [dg, db]
+        return (None, *grads, *pgrads)
+
+
 class _CBR(nn.Sequential):
     """nn.Sequential(Conv2d, BatchNorm2d, ReLU) with the reference's state_dict keys, executed as one node"""
 
@@ -120,6 +174,7 @@ _DEFER_NBT = [False]     # set by HRNet.forward: the blocks leave their num_batc
 # statistics passes already hidden on the branch streams: 70.0 vs 69.0 ms / step), so off here; ResNet-50: +1.8 %
 EPI_STATS = os.environ.get("SCAT_HRNET_EPI", "0") != "0"
 FUSED_BASIC = os.environ.get("SCAT_HRNET_FUSED", "1") != "0"   # 0: the per-layer autograd path, for A/B runs
+FUSED_EXCHANGE = os.environ.get("SCAT_HRNET_FUSED_X", "1") != "0"   # an exchange output's BatchNorms, upsamples, adds and ReLU: one node
 FUSED_CBR = os.environ.get("SCAT_HRNET_FUSED_CBR", "1") != "0"   # conv + BatchNorm + ReLU units as one node each
 EPI_STATS_CBR = os.environ.get("SCAT_HRNET_CBR_EPI", "1") != "0"   # ... with the BatchNorm sums from the convolution epilogue
 FUSED_BOTTLENECK = os.environ.get("SCAT_HRNET_FUSED_L1", "1") != "0"   # layer1's Bottlenecks on ResNet's block executor
@@ -218,6 +273,26 @@ class StageModule(nn.Module):
         self.relu = snn.ReLU(inplace=True)
 
     def _fuse(self, i, x):
+        if FUSED_EXCHANGE and x[0].is_cuda and len(self.branches) <= 4:
+            # the convolutions stay nodes of their own; everything after the last one of each term is one node
+            spec, tens, params = [], [], []
+            for j in range(len(self.branches)):
+                layer = self.fuse_layers[i][j]
+                if j == i:
+                    spec.append((None, 0))
+                    tens.append(x[j])
+                elif i < j:                                  # 1x1 convolution, BatchNorm, nearest upsample by 2^(j-i)
+                    spec.append((layer[1], j - i))
+                    tens.append(layer[0](x[j]))
+                    params += [layer[1].weight, layer[1].bias]
+                else:                                        # strided 3x3 chain: the last unit is convolution + BatchNorm
+                    h = x[j]
+                    for unit in layer[:-1]:
+                        h = unit(h)
+                    spec.append((layer[-1][1], 0))
+                    tens.append(layer[-1][0](h))
+                    params += [layer[-1][1].weight, layer[-1][1].bias]
+            return _FuseSumFn.apply(tuple(spec), *tens, *params)
         acc = self.fuse_layers[i][0](x[0])
         for j in range(1, len(self.branches)):
             acc = snn.add(acc, self.fuse_layers[i][j](x[j]))

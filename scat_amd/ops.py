@@ -852,6 +852,25 @@ def preprocess_u8(src, out_hw=(224, 224), hwc=False):
     return dst
 
 
+def fuse_sum(terms, relu=True):
+    """relu?(sum of terms), terms = [(tensor [B,C,H>>k,W>>k], scale|None, shift|None, k)] in the order they are added
+    (one pass; include/scat_hip.h scat_fuse_sum)."""
+    assert 1 <= len(terms) <= 4
+    k0 = [t for t in terms if t[3] == 0]
+    B, C, H, W = (k0[0][0].shape if k0 else tuple(terms[0][0].shape[:2]) + tuple(d << terms[0][3] for d in terms[0][0].shape[2:]))
+    ins, scs, shs, ks = [], [], [], []
+    for t, sc, sh, k in terms:
+        _chk(t, sc, sh)
+        assert tuple(t.shape) == (B, C, H >> k, W >> k), (tuple(t.shape), (B, C, H, W), k)
+        ins.append(t); scs.append(sc); shs.append(sh); ks.append(int(k))
+    pad = 4 - len(terms)
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=ins[0].device)
+    lib().scat_fuse_sum(*[_p(t) for t in ins + [None] * pad], *[_p(t) for t in scs + [None] * pad],
+                        *[_p(t) for t in shs + [None] * pad], *(ks + [0] * pad), len(terms), _p(out), B, C, H, W, int(relu),
+                        _stream())
+    return out
+
+
 def upsample_nearest_fwd(x, factor):
     _chk(x)
     B, C, H, W = x.shape

@@ -1198,3 +1198,27 @@ def test_batchnorm_last_arriver_finalize(ops, B, C, H):
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         two = torch.load(f)
     assert torch.equal(outs[0].cpu(), two)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(3, 32, 56, 56), (2, 64, 28, 28), (2, 16, 14, 14), (1, 8, 8, 12), (2, 8, 6, 10)])
+def test_fuse_sum_exchange_output(ops, B, C, H, W):
+    """scat_fuse_sum (models/hrnet.py:117-144, one output of an exchange unit): BatchNorm-normalised, nearest-upsampled
+    terms added in the given order + ReLU in one pass == the reference's chain of BatchNorm / Upsample / add / ReLU."""
+    v = lambda a: a.view(1, -1, 1, 1)
+    x0 = t(301, "x0", (B, C, H, W))
+    terms, ref = [(g(x0), None, None, 0)], x0.double()
+    for n, k in enumerate((1, 2, 0)):
+        if H % (1 << k) or W % (1 << k):
+            continue                                      # (14 x 14 maps have no branch four times coarser)
+        c = t(302 + n, "c", (B, C, H >> k, W >> k)) * (1.3 - 0.3 * n) + 0.2 * n
+        sc = torch.from_numpy(synth.uniform(310 + n, "s", (C,), 0.5, 1.5))
+        sh = torch.from_numpy(synth.uniform(320 + n, "h", (C,), -0.5, 0.5))
+        term = c.double() * v(sc.double()) + v(sh.double())
+        ref = ref + (F.interpolate(term, scale_factor=1 << k, mode="nearest") if k else term)
+        terms.append((g(c), g(sc), g(sh), k))
+    assert rel_err(ops.fuse_sum(terms, relu=True), F.relu(ref)) < 1e-6
+    # an upsampled term first, no ReLU
+    got = ops.fuse_sum([terms[1], terms[0]], relu=False)
+    c, sc, sh, k = terms[1]
+    ref2 = F.interpolate(c.cpu().double() * v(sc.cpu().double()) + v(sh.cpu().double()), scale_factor=2, mode="nearest") + x0.double()
+    assert rel_err(got, ref2) < 1e-6
