@@ -296,6 +296,11 @@ int scat_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, vo
 int scat_axpy(const float* a, const float* b, float alpha, float* y, int64_t n, void* stream);
 /* column sums: out[j] (+)= sum_i x[i*cols + j]  (bias gradients), fixed order */
 int scat_colsum(const float* x, float* out, int rows, int cols, int accumulate, void* stream);
+/* the same with a caller-owned scratch of scat_colsum_ws(rows, cols) bytes (0 for small inputs): tall matrices are summed in
+ * row slices by ~1024 workgroups instead of cols / 16, slices added in index order (bias gradients of the token mixers:
+ * models/vit.py:40-47 at HRNet's 24 672 x 196 tokens) */
+int64_t scat_colsum_ws(int rows, int cols);
+int scat_colsum_sliced(const float* x, float* out, int rows, int cols, int accumulate, void* ws, int64_t ws_bytes, void* stream);
 /* tokens: y[B,T,D] = x[B,T,D] + pe[T,D], then rows t in masked[] <- mask_token[D]   (hand_net.py:366-373) */
 int scat_tokens_fwd(const float* x, const float* pe, const float* mask_token, const int32_t* masked, int nmasked,
                     float* y, int B, int T, int D, void* stream);

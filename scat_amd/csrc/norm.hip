@@ -902,8 +902,63 @@ extern "C" int scat_layernorm_fwd(const float* x, const float* gamma, const floa
     return SCAT_OK;
 }
 
+// Tall matrices (HRNet's token mixer: 196 608 rows x 196 columns): cols / 16 workgroups cannot pull 150 MB fast enough
+// (13 workgroups: 80 us per sum).  Two sums (a and b, same shape) in row slices — grid (cols / 16, S), partial sums
+// part[which][slice][col] — and a finish that adds the slices in index order: fixed summation order, no atomics.
+template <bool TWO>
+__global__ __launch_bounds__(1024) void colsum2_part_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            float* __restrict__ part, int rows, int cols, int rps) {
+    __shared__ float sh[2][64][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + tx, S = gridDim.y, sl = blockIdx.y;
+    const int r0 = sl * rps, r1 = min(r0 + rps, rows);
+    float s0 = 0.f, s1 = 0.f;
+    if (j < cols) {
+        int i = r0 + ty;
+        for (; i + 3 * 64 < r1; i += 4 * 64) {
+            float u[4], v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u[q] = a[(int64_t)(i + q * 64) * cols + j];
+                v[q] = TWO ? b[(int64_t)(i + q * 64) * cols + j] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s0 += u[q]; s1 += v[q]; }
+        }
+        for (; i < r1; i += 64) { s0 += a[(int64_t)i * cols + j]; if (TWO) s1 += b[(int64_t)i * cols + j]; }
+    }
+    sh[0][ty][tx] = s0; sh[1][ty][tx] = s1;
+    __syncthreads();
+    for (int half = 32; half > 0; half >>= 1) {
+        if (ty < half) { sh[0][ty][tx] += sh[0][ty + half][tx]; sh[1][ty][tx] += sh[1][ty + half][tx]; }
+        __syncthreads();
+    }
+    if (ty == 0 && j < cols) {
+        part[((int64_t)0 * S + sl) * cols + j] = sh[0][0][tx];
+        if (TWO) part[((int64_t)1 * S + sl) * cols + j] = sh[1][0][tx];
+    }
+}
+__global__ __launch_bounds__(256) void colsum2_fin_kernel(const float* __restrict__ part, float* __restrict__ oa,
+                                                          float* __restrict__ ob, int S, int cols, int accumulate) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int q = 0; q < S; ++q) {
+        s0 += part[(int64_t)q * cols + j];
+        if (ob) s1 += part[((int64_t)S + q) * cols + j];
+    }
+    oa[j] = (accumulate ? oa[j] : 0.f) + s0;
+    if (ob) ob[j] = s1;
+}
+static int colsum2_slices(int rows, int cols) {
+    if ((int64_t)rows * cols < (1 << 22)) return 1;            // small: the one-launch-per-sum form
+    const int want = cdiv(1024, cdiv(cols, 16));                // ~1024 workgroups
+    return max(1, min(want, rows / 256));
+}
+
 extern "C" int64_t scat_layernorm_bwd_ws(int rows, int dim) {
-    return rows > 0 && dim > 0 ? (int64_t)rows * dim * sizeof(float) : 0;
+    if (!(rows > 0 && dim > 0)) return 0;
+    return (int64_t)rows * dim * sizeof(float) + (int64_t)2 * colsum2_slices(rows, dim) * dim * sizeof(float);
 }
 
 extern "C" int scat_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
@@ -918,9 +973,40 @@ extern "C" int scat_layernorm_bwd(const float* dy, const float* x, const float* 
     float* t = (float*)ws;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, t, rows,
                        dim);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim, 16)), dim3(1024), 0, st, (const float*)t, dgamma, rows, dim, 0);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim, 16)), dim3(1024), 0, st, dy, dbeta, rows, dim, 0);
+    const int S = colsum2_slices(rows, dim);
+    if (S > 1) {
+        float* part = t + (int64_t)rows * dim;
+        hipLaunchKernelGGL(colsum2_part_kernel<true>, dim3(cdiv(dim, 16), S), dim3(1024), 0, st, (const float*)t, dy, part, rows,
+                           dim, cdiv(rows, S));
+        hipLaunchKernelGGL(colsum2_fin_kernel, dim3(cdiv(dim, 256)), dim3(256), 0, st, (const float*)part, dgamma, dbeta, S, dim, 0);
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim, 16)), dim3(1024), 0, st, (const float*)t, dgamma, rows, dim, 0);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim, 16)), dim3(1024), 0, st, dy, dbeta, rows, dim, 0);
+    }
     SCAT_LAUNCH_CHECK("scat_layernorm_bwd");
+    return SCAT_OK;
+}
+
+extern "C" int scat_colsum(const float* x, float* out, int rows, int cols, int accumulate, void* stream);
+extern "C" int64_t scat_colsum_ws(int rows, int cols) {
+    const int S = rows > 0 && cols > 0 ? colsum2_slices(rows, cols) : 1;
+    return S > 1 ? (int64_t)S * cols * sizeof(float) : 0;
+}
+
+// the same sum with a caller-owned scratch of scat_colsum_ws(rows, cols) bytes: tall matrices are summed in row slices by
+// ~1024 workgroups (scat_colsum alone: cols / 16 workgroups), slices added in index order
+extern "C" int scat_colsum_sliced(const float* x, float* out, int rows, int cols, int accumulate, void* ws, int64_t ws_bytes,
+                                  void* stream) {
+    SCAT_REQUIRE(x && out && rows > 0 && cols > 0, SCAT_E_ARG, "scat_colsum_sliced: bad argument");
+    const int S = colsum2_slices(rows, cols);
+    if (S <= 1) return scat_colsum(x, out, rows, cols, accumulate, stream);
+    SCAT_REQUIRE(ws && ws_bytes >= scat_colsum_ws(rows, cols), SCAT_E_WORKSPACE, "scat_colsum_sliced: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum2_part_kernel<false>, dim3(cdiv(cols, 16), S), dim3(1024), 0, st, x, (const float*)nullptr,
+                       (float*)ws, rows, cols, cdiv(rows, S));
+    hipLaunchKernelGGL(colsum2_fin_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, (const float*)ws, out, (float*)nullptr, S,
+                       cols, accumulate);
+    SCAT_LAUNCH_CHECK("scat_colsum_sliced");
     return SCAT_OK;
 }
 

@@ -513,7 +513,12 @@ def colsum(x2d, out=None, accumulate=False):
     _chk(x2d, out)
     rows, cols = x2d.shape
     o = out if out is not None else torch.empty((cols,), dtype=torch.float32, device=x2d.device)
-    lib().scat_colsum(_p(x2d), _p(o), rows, cols, int(accumulate), _stream())
+    nws = lib().scat_colsum_ws(rows, cols)
+    if nws > 0:          # tall: row slices over ~1024 workgroups, then the slices in index order
+        ws = workspace(nws, x2d.device, "colsum")
+        lib().scat_colsum_sliced(_p(x2d), _p(o), rows, cols, int(accumulate), _p(ws), ws.numel(), _stream())
+    else:
+        lib().scat_colsum(_p(x2d), _p(o), rows, cols, int(accumulate), _stream())
     return o
 
 

@@ -666,7 +666,7 @@ def test_pools(ops):
     assert rel_err(ops.avgpool_bwd(g(df), fg, tuple(x4.shape)), x4.grad) < 1e-6
 
 
-@pytest.mark.parametrize("rows,dim", [(84, 784), (2016, 392), (40, 196), (7, 50)])
+@pytest.mark.parametrize("rows,dim", [(84, 784), (2016, 392), (40, 196), (7, 50), (24001, 196)])   # (the last: sliced column sums)
 def test_layernorm(ops, rows, dim):
     x = (t(31, "x", (rows, dim)) * 2 + 0.3).requires_grad_(True)
     gm = torch.from_numpy(synth.uniform(32, "g", (dim,), 0.7, 1.3)).requires_grad_(True)
@@ -1222,3 +1222,17 @@ def test_fuse_sum_exchange_output(ops, B, C, H, W):
     c, sc, sh, k = terms[1]
     ref2 = F.interpolate(c.cpu().double() * v(sc.cpu().double()) + v(sh.cpu().double()), scale_factor=2, mode="nearest") + x0.double()
     assert rel_err(got, ref2) < 1e-6
+
+
+@pytest.mark.parametrize("rows,cols", [(24672, 196), (24001, 392), (70000, 61), (5000, 196)])
+def test_colsum_tall(ops, rows, cols):
+    """bias gradients of the token mixers at HRNet's token count (models/vit.py:40-47, 96 x 257 tokens): tall matrices are
+    summed in row slices (scat_colsum_sliced), small ones by the one-launch form; also accumulating; same bits twice"""
+    x = t(401, "x", (rows, cols)) + 0.25
+    ref = x.double().sum(0)
+    got = ops.colsum(g(x))
+    assert rel_err(got, ref) < 2e-6
+    assert torch.equal(got, ops.colsum(g(x)))
+    acc = g(torch.ones(cols))
+    ops.colsum(g(x), out=acc, accumulate=True)
+    assert rel_err(acc, ref + 1.0) < 2e-6
