@@ -458,6 +458,109 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_fin_kernel(const float* __
     }
 }
 
+// Reduce AND apply in one launch when a channel's elements fit the registers of its workgroup (B * HW <= 1024 * NIT * V:
+// the 14 x 14 and 7 x 7 planes at batch 96): the masked gradient and x are read ONCE, held while the two sums go through
+// the same reduction as above (same thread -> element map, same tree: the same bits as reduce + apply), and dx / dres are
+// written from the registers — 3 tensor passes instead of 5 and one launch instead of two.
+template <int V, int NIT>
+__global__ __launch_bounds__(1024) void bn_bwd_onepass_kernel(const float* dy, const float* __restrict__ x,
+                                                              const float* __restrict__ yout,
+                                                              const uint8_t* __restrict__ ymask, int relu,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, int B, int C, int HW,
+                                                              FastDiv dHWv, double count, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef, float* dx,
+                                                              float* dres, int dres_acc) {
+    const int c = blockIdx.x;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const int hwv = HW / V, nv = B * hwv;
+    const bool has_m = V == 4 && ymask != nullptr;
+    const bool has_y = yout != nullptr || has_m;
+    float gk[NIT][V], xk[NIT][V];
+    double s1 = 0, s2 = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = threadIdx.x + it * 1024;
+        const bool live = idx < nv;
+        const int n = live ? (int)dHWv.div((uint32_t)idx) : 0, i = live ? idx - n * hwv : 0;
+        const int64_t off = ((int64_t)n * C + c) * HW + i * V;
+        float xv[V], gv[V], yv[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) { xv[q] = gv[q] = yv[q] = 0.f; }
+        if (live) {
+            if (V == 4) {
+                float4 t = *(const float4*)(x + off); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                t = *(const float4*)(dy + off); gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+                if (has_m) {
+                    const uint32_t m = ymask[off >> 2];
+                    yv[0] = (float)(m & 1u); yv[1] = (float)((m >> 1) & 1u); yv[2] = (float)((m >> 2) & 1u); yv[3] = (float)((m >> 3) & 1u);
+                } else if (has_y) { t = *(const float4*)(yout + off); yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w; }
+            } else {
+                xv[0] = x[off]; gv[0] = dy[off];
+                if (has_y) yv[0] = yout[off];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const float g = live ? bn_mask(gv[q], xv[q], has_y ? yv[q] : 0.f, has_y, relu, sc, sh) : 0.f;
+            gk[it][q] = g; xk[it][q] = xv[q];
+            if (live) {
+                s1 += g;
+                s2 += (double)g * ((xv[q] - mu) * is);
+            }
+        }
+    }
+    __shared__ double shm[34];
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { shm[w] = s1; shm[16 + w] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { a += shm[k]; b += shm[16 + k]; }
+        dbeta[c] = (float)a;
+        dgamma[c] = (float)b;
+        const float k1 = (float)(a / count), k2 = (float)(b / count);
+        coef[2 * c] = k1;
+        coef[2 * c + 1] = k2;
+        shm[32] = k1; shm[33] = k2;
+    }
+    __syncthreads();
+    const float k1 = (float)shm[32], k2 = (float)shm[33], gi = gamma[c] * is;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = threadIdx.x + it * 1024;
+        if (idx >= nv) break;
+        const int n = (int)dHWv.div((uint32_t)idx), i = idx - n * hwv;
+        const int64_t off = ((int64_t)n * C + c) * HW + i * V;
+        float ov[V], rv[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) rv[q] = 0.f;
+        if (dres && dres_acc) {
+            if (V == 4) { const float4 t = *(const float4*)(dres + off); rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
+            else rv[0] = dres[off];
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const float xh = (xk[it][q] - mu) * is;
+            ov[q] = gi * (gk[it][q] - k1 - xh * k2);
+            rv[q] += gk[it][q];
+        }
+        if (V == 4) {
+            *(float4*)(dx + off) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            if (dres) *(float4*)(dres + off) = make_float4(rv[0], rv[1], rv[2], rv[3]);
+        } else {
+            dx[off] = ov[0];
+            if (dres) dres[off] = rv[0];
+        }
+    }
+}
+
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, int S, double count,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ coef) {
@@ -828,6 +931,22 @@ extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, 
     SCAT_REQUIRE(!y_mask || vec, SCAT_E_SHAPE, "scat_bn_bwd: the sign mask needs HW % 4 == 0 and 16-B aligned tensors");
     SCAT_REQUIRE(!(y_mask && y_out), SCAT_E_ARG, "scat_bn_bwd: pass the output OR its sign mask");
     static const int fused_min_c = [] { const char* e = getenv("SCAT_BN_FUSED_MIN_C"); return e ? atoi(e) : 256; }();
+    // small planes: one workgroup per channel holds its elements in registers (reduce + apply in one launch)
+    static const int onepass = [] { const char* e = getenv("SCAT_BN_ONEPASS"); return e ? atoi(e) : 1; }();
+    const int64_t nvc = (int64_t)B * HW / (vec ? 4 : 1);
+    if (onepass && C >= 64 && nvc <= 1024 * 8) {
+        const FastDiv dv = FastDiv::make(vec ? HW / 4 : HW);
+        const double cnt = (double)B * HW;
+#define SCAT_BN_ONEPASS(V, NIT)                                                                                              \
+        hipLaunchKernelGGL((bn_bwd_onepass_kernel<V, NIT>), dim3(C), dim3(1024), 0, st, dy, x, y_out, vec ? y_mask : nullptr, \
+                           relu, scale, shift, save_mean, save_invstd, gamma, B, C, HW, dv, cnt, dgamma, dbeta, coef, dx,     \
+                           dres, dres_accumulate)
+        if (vec) { if (nvc <= 1024 * 2) SCAT_BN_ONEPASS(4, 2); else if (nvc <= 1024 * 5) SCAT_BN_ONEPASS(4, 5); else SCAT_BN_ONEPASS(4, 8); }
+        else { if (nvc <= 1024 * 2) SCAT_BN_ONEPASS(1, 2); else if (nvc <= 1024 * 5) SCAT_BN_ONEPASS(1, 5); else SCAT_BN_ONEPASS(1, 8); }
+#undef SCAT_BN_ONEPASS
+        SCAT_LAUNCH_CHECK("scat_bn_bwd");
+        return SCAT_OK;
+    }
     if (C >= fused_min_c) {
         if (vec)
             hipLaunchKernelGGL(bn_bwd_reduce_fin_kernel<4>, dim3(C), dim3(1024), 0, st, dy, x, y_out, y_mask, relu, scale,
