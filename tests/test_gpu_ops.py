@@ -1236,3 +1236,46 @@ def test_colsum_tall(ops, rows, cols):
     acc = g(torch.ones(cols))
     ops.colsum(g(x), out=acc, accumulate=True)
     assert rel_err(acc, ref + 1.0) < 2e-6
+
+
+@pytest.mark.parametrize("B,C,H", [(96, 256, 14), (96, 64, 7), (5, 128, 14), (3, 70, 9)])
+def test_batchnorm_backward_one_pass(ops, B, C, H):
+    """Small planes: the BatchNorm backward reduces and applies in one launch from registers (csrc/norm.hip
+    bn_bwd_onepass_kernel) — against fp64 autograd, with the residual-gradient output, and bit for bit the two-launch
+    form's result (SCAT_BN_ONEPASS=0 in a child process)."""
+    import subprocess
+    import sys
+    import tempfile
+    x = t(501, "x", (B, C, H, H)) * 1.4 - 0.3
+    dy = t(502, "dy", (B, C, H, H))
+    gamma = torch.from_numpy(synth.uniform(503, "g", (C,), 0.5, 1.5))
+    beta = torch.from_numpy(synth.uniform(504, "b", (C,), -0.3, 0.3))
+    xg, dyg, gg, bg = g(x), g(dy), g(gamma), g(beta)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, invstd, scale, shift = ops.bn_train_stats(xg, gg, bg, rm, rv)
+    res = torch.full_like(dyg, 0.5)
+    dxg, dgg, dbg = ops.bn_bwd(dyg, xg, None, True, scale, shift, mean, invstd, gg, dres=res)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5))
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(yr, (xr, gr, br), dy.double())
+    assert rel_err(dxg, dx_ref) < 2e-5 and rel_err(dgg, dg_ref) < 2e-5 and rel_err(dbg, db_ref) < 2e-5
+    assert rel_err(res, dy.double() * (yr > 0)) < 1e-6          # dres: the masked gradient itself
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_ops as T\nfrom scat_amd import ops, synth\n"
+            "B, C, H = %d, %d, %d\n"
+            "x = T.g(T.t(501, 'x', (B, C, H, H)) * 1.4 - 0.3); dy = T.g(T.t(502, 'dy', (B, C, H, H)))\n"
+            "gm = T.g(torch.from_numpy(synth.uniform(503, 'g', (C,), 0.5, 1.5))); bt = T.g(torch.from_numpy(synth.uniform(504, 'b', (C,), -0.3, 0.3)))\n"
+            "rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')\n"
+            "mean, invstd, scale, shift = ops.bn_train_stats(x, gm, bt, rm, rv)\n"
+            "dx, dg, db = ops.bn_bwd(dy, x, None, True, scale, shift, mean, invstd, gm)\n"
+            "torch.save((dx.cpu(), dg.cpu(), db.cpu()), sys.argv[1])\n") % (root, os.path.join(root, "tests"), B, C, H)
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "two.pt")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, SCAT_BN_ONEPASS="0"), capture_output=True,
+                           text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        dx2, dg2, db2 = torch.load(f)
+    dx1, dg1, db1 = ops.bn_bwd(dyg, xg, None, True, scale, shift, mean, invstd, gg)
+    assert torch.equal(dx1.cpu(), dx2) and torch.equal(dg1.cpu(), dg2) and torch.equal(db1.cpu(), db2)
