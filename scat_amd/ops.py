@@ -85,6 +85,8 @@ def workspace(nbytes: int, device, slot: str = "default") -> torch.Tensor:
     return buf
 
 
+BN_ONEPASS = os.environ.get("SCAT_BN_ONEPASS", "1") != "0"   # (the switch is read by the library; here for the byte count)
+
 # kinds of scat_wprep_jobs (include/scat_hip.h SCAT_WPREP_*)
 WPREP_CONV1X1_FWD, WPREP_CONV1X1_DGRAD, WPREP_CONV3X3_FWD, WPREP_CONV3X3_DGRAD, WPREP_FWD_SPLIT, WPREP_DGRAD_S2 = range(6)
 WPREP = os.environ.get("SCAT_WPREP", "1") != "0"   # 0: every convolution re-lays its weights itself (A/B runs)
@@ -594,6 +596,9 @@ def bn_bwd(dy, x, y_out, relu, scale, shift, save_mean, save_invstd, gamma, dgam
     # sign comes from y_out (4 B) or its mask (1 bit) in both passes
     sign = 8.0 if y_out is not None else (0.0625 if y_mask is not None else 0.0)
     nb = x.numel() * (8.0 + 12.0 + sign + (4.0 if dres is not None and dres is not dy else 0.0))
+    # small planes take the one-launch form (csrc/norm.hip bn_bwd_onepass_kernel): every tensor is read once
+    if BN_ONEPASS and C >= 64 and B * H * W // (4 if (H * W) % 4 == 0 else 1) <= 8192:
+        nb = x.numel() * (12.0 + sign / 2 + (4.0 if dres is not None and dres is not dy else 0.0))
     _prof_hbm("bn_bwd" + ("_res" if dres is not None else ""), nb, lib().scat_bn_bwd, _p(dy), _p(x), _p(y_out),
               _p(y_mask), int(relu), _p(scale), _p(shift), _p(save_mean), _p(save_invstd), _p(gamma), _p(dgamma),
               _p(dbeta), _p(dx), _p(dres), int(dres_accumulate), B, C, H * W, _p(ws), ws.numel(), _stream())
