@@ -93,10 +93,20 @@ def _main(device):
     return torch.cuda.default_stream(_dev(device))
 
 
+_WARNED = [False]
+
+
 def bind(device, roles, priority=0):
     """Create the streams of ``roles`` (those not bound yet), in the order given."""
     device = _dev(device)
     b = bound(device)
+    if not _WARNED[0]:
+        _WARNED[0] = True
+        q = os.environ.get("GPU_MAX_HW_QUEUES", "")
+        if q.isdigit() and int(q) > 4:
+            import warnings
+            warnings.warn(f"scat_amd: GPU_MAX_HW_QUEUES={q}: with more than four hardware queues per process the train step "
+                          "was measured 30 % slower on MI355X (profiles/r03_dp_queues.txt); unset it", RuntimeWarning)
     for r in roles:
         if r in b:
             continue
