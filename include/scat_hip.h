@@ -225,6 +225,13 @@ int scat_bn_bwd(const float* dy, const float* x, const float* y_out, const uint8
                 float* dgamma, float* dbeta, float* dx, float* dres, int dres_accumulate, int B, int C, int HW,
                 void* ws, int64_t ws_bytes, void* stream);
 
+/* the same backward for the stem (models/resnet.py:108-112 conv1 -> bn1 -> relu -> maxpool): dy is the gradient of the
+ * 3x3 / stride-2 / pad-1 max-pool's OUTPUT [B,C,H/2,W/2] with its arg-max taps idx (scat_maxpool3x3s2_fwd); the scattered
+ * full-resolution gradient is never written.  dx[B,C,H,W].  Even H, W % 4 == 0.  ws: scat_bn_ws(B, C, H*W). */
+int scat_bn_bwd_maxpool(const float* dy_pooled, const int8_t* idx, const float* x, int relu, const float* scale,
+                        const float* shift, const float* save_mean, const float* save_invstd, const float* gamma,
+                        float* dgamma, float* dbeta, float* dx, int B, int C, int H, int W, void* ws, int64_t ws_bytes,
+                        void* stream);
 /* BatchNorm backward split in two so that its second half never touches memory: this call masks dy IN PLACE
  * (g = dy * mask; g is also the residual branch's gradient), reduces the per-channel sums and emits
  * coef3[3*C] = (ca | cb | cc) with  dx = ca*g + cb*x + cc;  the consumers of dx apply that while loading their

@@ -401,6 +401,106 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------- BatchNorm backward straight from a max-pool's gradient
+//
+// The stem (models/resnet.py:108-112: conv1 -> bn1 -> relu -> maxpool 3x3 / 2) used to scatter the pooled gradient into
+// the full-resolution map (write 308 MB at batch 96), reduce over that map and x (read 616 MB) and apply (read 616 MB,
+// write 308 MB).  The gradient of bn1's output is non-zero only at arg-max positions, so:
+//   * the two sums run over the POOLED grid: window q contributes g_q at its arg-max pixel p(q) — mask and x-hat taken
+//     from x[p(q)] (a gather inside a 3 x 3 window: the same cache lines the neighbours touch);
+//   * the apply pass rebuilds the scattered gradient of a 2 x 2 input quad from the six windows that see it (the
+//     max-pool backward's own arithmetic, pool.hip) and writes dx directly.
+// 96 + 96 + 308 MB read and 308 MB written instead of 1.9 GB.  Even H, W with W % 4 == 0 (the stem: 112 x 112 -> 56 x 56).
+__global__ __launch_bounds__(256) void bn_bwd_pool_reduce_kernel(const float* __restrict__ dyp, const int8_t* __restrict__ idx,
+                                                                 const float* __restrict__ x, int relu,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, int B, int C, int H, int W,
+                                                                 int S, double* __restrict__ part, BnFin f) {
+    const int c = blockIdx.x, s = blockIdx.y;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const int OH = H / 2, OW = W / 2, nimg = (B - s + S - 1) / S, ohw = OH * OW;
+    double s1 = 0, s2 = 0;
+    for (int e = threadIdx.x; e < nimg * ohw; e += 256) {
+        const int nl = e / ohw, q = e - nl * ohw;
+        const int a = q / OW, b = q - a * OW;
+        const int64_t nc = (int64_t)(s + nl * S) * C + c;
+        const float g0 = dyp[nc * ohw + q];
+        const int t = idx[nc * ohw + q];
+        const int iy = 2 * a - 1 + t / 3, ix = 2 * b - 1 + t % 3;          // (the arg-max is always inside the map)
+        const float xv = x[(nc * H + iy) * W + ix];
+        const float g = bn_mask(g0, xv, 0.f, false, relu, sc, sh);
+        s1 += g;
+        s2 += (double)g * ((xv - mu) * is);
+    }
+    __shared__ double shm[8];
+    block_sum2(s1, s2, shm);
+    if (f.slots) {
+        if (bn_publish(f.slots + (int64_t)c * S, f.claim + c, s, S, f.tag, s1, s2)) bn_bwd_finish(c, C, s1, s2, f);
+    } else if (threadIdx.x == 0) {
+        part[((int64_t)c * S + s) * 2 + 0] = s1;
+        part[((int64_t)c * S + s) * 2 + 1] = s2;
+    }
+}
+
+// one thread = two horizontally adjacent 2 x 2 input quads (pool.hip maxpool_bwd_quad_kernel), then the BatchNorm backward
+__global__ __launch_bounds__(256) void bn_bwd_pool_apply_kernel(const float* __restrict__ dyp, const int8_t* __restrict__ idx,
+                                                                const float* __restrict__ x, int relu,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ coef, float* __restrict__ dx,
+                                                                int64_t total, int C, int W, int OH, int OW) {
+    const int QW = OW / 2;
+    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+        const int b2 = e % QW;
+        const int64_t r = e / QW;
+        const int a = r % OH;
+        const int64_t nc = r / OH;
+        const int c = (int)(nc % C);
+        const float* g = dyp + nc * OH * OW;
+        const int8_t* id = idx + nc * OH * OW;
+        const int b = 2 * b2;
+        float gv[2][3];
+        int iv[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const bool ok = (a + u < OH) && (b + v < OW);
+                const int q = ok ? (a + u) * OW + b + v : 0;
+                gv[u][v] = ok ? g[q] : 0.f;
+                iv[u][v] = ok ? (int)id[q] : -1;
+            }
+        float top[4], bot[4];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            top[2 * v] = iv[0][v] == 4 ? gv[0][v] : 0.f;
+            top[2 * v + 1] = (iv[0][v] == 5 ? gv[0][v] : 0.f) + (iv[0][v + 1] == 3 ? gv[0][v + 1] : 0.f);
+            bot[2 * v] = (iv[0][v] == 7 ? gv[0][v] : 0.f) + (iv[1][v] == 1 ? gv[1][v] : 0.f);
+            bot[2 * v + 1] = (iv[0][v] == 8 ? gv[0][v] : 0.f) + (iv[0][v + 1] == 6 ? gv[0][v + 1] : 0.f) +
+                             (iv[1][v] == 2 ? gv[1][v] : 0.f) + (iv[1][v + 1] == 0 ? gv[1][v + 1] : 0.f);
+        }
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        const float k1 = coef[2 * c], k2 = coef[2 * c + 1], gi = gamma[c] * is;
+        const int64_t off = (nc * 2 * OH + 2 * a) * W + 2 * b;
+        const float4 x0 = *(const float4*)(x + off), x1 = *(const float4*)(x + off + W);
+        const float xt[4] = {x0.x, x0.y, x0.z, x0.w}, xb[4] = {x1.x, x1.y, x1.z, x1.w};
+        float ot[4], ob[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float gt = bn_mask(top[q], xt[q], 0.f, false, relu, sc, sh), gb = bn_mask(bot[q], xb[q], 0.f, false, relu, sc, sh);
+            ot[q] = gi * (gt - k1 - (xt[q] - mu) * is * k2);
+            ob[q] = gi * (gb - k1 - (xb[q] - mu) * is * k2);
+        }
+        *(float4*)(dx + off) = make_float4(ot[0], ot[1], ot[2], ot[3]);
+        *(float4*)(dx + off + W) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+    }
+}
+
 // The same reduction with its finalize in ONE launch when the channels alone fill the GPU (one 1024-thread workgroup
 // per channel): the reduce -> finalize -> apply chain of every BatchNorm backward sits on the data-gradient critical path.
 template <int V>
@@ -980,6 +1080,38 @@ extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, 
                            FastDiv::make(HW), FastDiv::make(C));
     }
     SCAT_LAUNCH_CHECK("scat_bn_bwd");
+    return SCAT_OK;
+}
+
+// dx[B,C,H,W] = BatchNorm(+ReLU) backward of the gradient that a 3x3 / stride-2 / pad-1 max-pool's backward would scatter from
+// dy_pooled[B,C,H/2,W/2] with the arg-max taps idx (scat_maxpool3x3s2_fwd), without materialising that gradient.
+extern "C" int scat_bn_bwd_maxpool(const float* dy_pooled, const int8_t* idx, const float* x, int relu, const float* scale,
+                                   const float* shift, const float* save_mean, const float* save_invstd,
+                                   const float* gamma, float* dgamma, float* dbeta, float* dx, int B, int C, int H, int W,
+                                   void* ws, int64_t ws_bytes, void* stream) {
+    SCAT_REQUIRE(dy_pooled && idx && x && scale && shift && save_mean && save_invstd && gamma && dgamma && dbeta && dx,
+                 SCAT_E_ARG, "scat_bn_bwd_maxpool: null pointer");
+    SCAT_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 4 == 0, SCAT_E_SHAPE,
+                 "scat_bn_bwd_maxpool: needs even H and W % 4 == 0");
+    SCAT_REQUIRE((((uintptr_t)x | (uintptr_t)dx) & 15) == 0, SCAT_E_SHAPE, "scat_bn_bwd_maxpool: 16-B aligned tensors");
+    SCAT_REQUIRE(ws && ws_bytes >= scat_bn_ws(B, C, H * W), SCAT_E_WORKSPACE, "scat_bn_bwd_maxpool: workspace too small");
+    SCAT_REQUIRE(fits_i32((int64_t)B * C * H * W), SCAT_E_SHAPE, "scat_bn_bwd_maxpool: tensor exceeds 2^31 elements");
+    const int S = bn_splits(B, C);
+    double* part = (double*)ws;
+    float* coef = bn_ws_coef(ws, C, S);
+    hipStream_t st = (hipStream_t)stream;
+    BnFin f = bn_fin_base(ws, C, S, (double)B * H * W);
+    f.dgamma = dgamma; f.dbeta = dbeta; f.coef = coef; f.coef3 = 0;
+    hipLaunchKernelGGL(bn_bwd_pool_reduce_kernel, dim3(C, S), dim3(256), 0, st, dy_pooled, idx, x, relu, scale, shift, save_mean,
+                       save_invstd, B, C, H, W, S, part, f);
+    if (!f.slots)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
+                           (double)B * H * W, dgamma, dbeta, coef);
+    const int OH = H / 2, OW = W / 2;
+    const int64_t total = (int64_t)B * C * OH * (OW / 2);
+    hipLaunchKernelGGL(bn_bwd_pool_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy_pooled, idx, x, relu, scale, shift,
+                       save_mean, save_invstd, gamma, (const float*)coef, dx, total, C, W, OH, OW);
+    SCAT_LAUNCH_CHECK("scat_bn_bwd_maxpool");
     return SCAT_OK;
 }
 

@@ -87,6 +87,7 @@ BNB_MIN_H = int(os.environ.get("SCAT_BNB_MIN_H", "28"))   # fold bn3 only where 
 BNB = os.environ.get("SCAT_BNB", "1") != "0"   # fold bn3's backward apply into conv3's gradient kernels
 SUBSAMPLE = os.environ.get("SCAT_SUBSAMPLE", "1") != "0"   # pack the input of the 1x1/stride-2 shortcuts (stride-1 kernels)
 SIDE_SHORTCUT = os.environ.get("SCAT_SIDE_SHORTCUT", "1") != "0"   # forward: the shortcut convolution beside conv1..conv3 (own stream)
+STEM_FUSED_BWD = os.environ.get("SCAT_STEM_FUSED_BWD", "1") != "0"   # max-pool backward inside bn1's backward (stem)
 SIDE_WGRAD = os.environ.get("SCAT_SIDE_WGRAD", "1") != "0"   # bench.py clears it for its serialized, per-kernel-timed step
 
 
@@ -494,9 +495,14 @@ class _BackboneFn(torch.autograd.Function):
             return (dcur, None, None, *[grads.get(p) for p in net._flat_params])
         # ---- stem: maxpool <- relu <- bn1 <- conv1
         x, c0, s0, idx0 = ctx.stem
-        da0 = ops.maxpool_bwd(dcur, idx0, tuple(c0.shape))
-        dc0, dg, db = ops.bn_bwd(da0, c0, None, True, s0.scale, s0.shift, s0.mean, s0.invstd, net.bn1.weight,
-                                 gbuf(net.bn1.weight), gbuf(net.bn1.bias), dx=da0)
+        if STEM_FUSED_BWD and c0.shape[2] % 2 == 0 and c0.shape[3] % 4 == 0 and dcur.is_contiguous():
+            # the max-pool's backward folded into bn1's: its 308 MB scattered gradient is never written or re-read
+            dc0, dg, db = ops.bn_bwd_maxpool(dcur, idx0, c0, True, s0.scale, s0.shift, s0.mean, s0.invstd, net.bn1.weight,
+                                             gbuf(net.bn1.weight), gbuf(net.bn1.bias))
+        else:
+            da0 = ops.maxpool_bwd(dcur, idx0, tuple(c0.shape))
+            dc0, dg, db = ops.bn_bwd(da0, c0, None, True, s0.scale, s0.shift, s0.mean, s0.invstd, net.bn1.weight,
+                                     gbuf(net.bn1.weight), gbuf(net.bn1.bias), dx=da0)
         put(net.bn1.weight, dg), put(net.bn1.bias, db)
         put(net.conv1.weight, wgrad(dc0, x, net.conv1.weight, 2, 3))
         join()

@@ -605,6 +605,25 @@ def bn_bwd(dy, x, y_out, relu, scale, shift, save_mean, save_invstd, gamma, dgam
     return dx, dgamma, dbeta
 
 
+def bn_bwd_maxpool(dy_pooled, idx, x, relu, scale, shift, save_mean, save_invstd, gamma, dgamma=None, dbeta=None):
+    """BatchNorm(+ReLU) backward of the gradient a 3x3 / stride-2 max-pool's backward would scatter from ``dy_pooled`` with
+    its arg-max taps ``idx`` (the stem: conv1 -> bn1 -> relu -> maxpool), without materialising that gradient.
+    -> (dx[B,C,H,W], dgamma, dbeta)"""
+    _chk(dy_pooled, x, scale, shift, save_mean, save_invstd, gamma, dgamma, dbeta)
+    B, C, H, W = x.shape
+    assert tuple(dy_pooled.shape) == (B, C, H // 2, W // 2) and idx.shape == dy_pooled.shape and idx.dtype == torch.int8
+    dx = torch.empty_like(x)
+    dgamma = dgamma if dgamma is not None else torch.empty_like(gamma)
+    dbeta = dbeta if dbeta is not None else torch.empty_like(gamma)
+    ws = workspace(lib().scat_bn_ws(B, C, H * W), x.device)
+    # algorithmic traffic: the pooled gradient + taps twice, a gather of x at the arg-max pixels, x once, dx once
+    nb = dy_pooled.numel() * (2 * 5.0 + 4.0) + x.numel() * 8.0
+    _prof_hbm("bn_bwd_maxpool", nb, lib().scat_bn_bwd_maxpool, _p(dy_pooled), _p(idx), _p(x), int(relu), _p(scale), _p(shift),
+              _p(save_mean), _p(save_invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dx), B, C, H, W, _p(ws), ws.numel(),
+              _stream())
+    return dx, dgamma, dbeta
+
+
 def bn_bwd_pre(dy, x, relu, scale, shift, save_mean, save_invstd, gamma, dgamma=None, dbeta=None, y_out=None,
                y_mask=None, dy_add=None):
     """First half of a BatchNorm backward: dy becomes the masked gradient g IN PLACE; returns (coef3[3,C], dgamma,

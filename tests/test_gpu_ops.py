@@ -1279,3 +1279,28 @@ def test_batchnorm_backward_one_pass(ops, B, C, H):
         dx2, dg2, db2 = torch.load(f)
     dx1, dg1, db1 = ops.bn_bwd(dyg, xg, None, True, scale, shift, mean, invstd, gg)
     assert torch.equal(dx1.cpu(), dx2) and torch.equal(dg1.cpu(), dg2) and torch.equal(db1.cpu(), db2)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(4, 64, 112, 112), (3, 16, 8, 12), (2, 8, 6, 4), (5, 70, 10, 8)])
+def test_batchnorm_backward_through_maxpool(ops, B, C, H, W):
+    """scat_bn_bwd_maxpool (the stem, models/resnet.py:108-112): bn1's backward taken straight from the max-pool's output
+    gradient and arg-max taps == max-pool backward followed by the BatchNorm backward (the library's own two-step path,
+    and fp64 autograd of batch_norm -> relu -> max_pool2d)."""
+    x = t(601, "x", (B, C, H, W)) * 1.2 + 0.1
+    gamma = torch.from_numpy(synth.uniform(603, "g", (C,), 0.5, 1.5))
+    beta = torch.from_numpy(synth.uniform(604, "b", (C,), -0.3, 0.3))
+    xg, gg, bg = g(x), g(gamma), g(beta)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, invstd, scale, shift = ops.bn_train_stats(xg, gg, bg, rm, rv)
+    y, idx = ops.maxpool_fwd(xg, scale, shift, True)
+    dy = t(602, "dy", tuple(y.shape))
+    dyg = g(dy)
+    dx1, dg1, db1 = ops.bn_bwd_maxpool(dyg, idx, xg, True, scale, shift, mean, invstd, gg)
+    da = ops.maxpool_bwd(dyg, idx, tuple(x.shape))
+    dx2, dg2, db2 = ops.bn_bwd(da, xg, None, True, scale, shift, mean, invstd, gg)
+    assert rel_err(dx1, dx2) < 1e-6 and rel_err(dg1, dg2) < 1e-6 and rel_err(db1, db2) < 1e-6
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = F.max_pool2d(F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)), 3, 2, 1)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(yr, (xr, gr, br), dy.double())
+    assert rel_err(dx1, dx_ref) < 2e-5 and rel_err(dg1, dg_ref) < 2e-5 and rel_err(db1, db_ref) < 2e-5
