@@ -427,8 +427,10 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_reduce_kernel(const float* __
         const int a = q / OW, b = q - a * OW;
         const int64_t nc = (int64_t)(s + nl * S) * C + c;
         const float g0 = dyp[nc * ohw + q];
-        const int t = idx[nc * ohw + q];
-        const int iy = 2 * a - 1 + t / 3, ix = 2 * b - 1 + t % 3;          // (the arg-max is always inside the map)
+        // (a tap written by scat_maxpool3x3s2_fwd is 0..8 and points inside the map; anything else — an index buffer nobody
+        //  filled — is clamped: a wrong number, never an access outside x)
+        const int t = min(max((int)idx[nc * ohw + q], 0), 8);
+        const int iy = min(max(2 * a - 1 + t / 3, 0), H - 1), ix = min(max(2 * b - 1 + t % 3, 0), W - 1);
         const float xv = x[(nc * H + iy) * W + ix];
         const float g = bn_mask(g0, xv, 0.f, false, relu, sc, sh);
         s1 += g;

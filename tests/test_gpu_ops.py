@@ -1304,3 +1304,15 @@ def test_batchnorm_backward_through_maxpool(ops, B, C, H, W):
     yr = F.max_pool2d(F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)), 3, 2, 1)
     dx_ref, dg_ref, db_ref = torch.autograd.grad(yr, (xr, gr, br), dy.double())
     assert rel_err(dx1, dx_ref) < 2e-5 and rel_err(dg1, dg_ref) < 2e-5 and rel_err(db1, db_ref) < 2e-5
+
+
+def test_batchnorm_backward_through_maxpool_survives_garbage_taps(ops):
+    """an arg-max buffer nobody filled (every byte value) must give wrong numbers, never an access outside x"""
+    B, C, H, W = 2, 8, 12, 16
+    x = g(t(611, "x", (B, C, H, W)))
+    dy = g(t(612, "dy", (B, C, H // 2, W // 2)))
+    idx = torch.arange(B * C * (H // 2) * (W // 2), device=DEV).to(torch.int8).view(B, C, H // 2, W // 2)   # -128 .. 127
+    one, zero = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    dx, dg, db = ops.bn_bwd_maxpool(dy, idx, x, True, one, zero, zero, one, one)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx).all() and torch.isfinite(dg).all()
