@@ -80,9 +80,17 @@ class Step:
         if config == "hrnet_w32":
             # the reference has no trainer for this wrapper (train.py builds EncoderTransformer only, train.py:49-57)
             # and its 61 outputs are MANO parameters, not joints: the step is forward + a fixed linear functional of
-            # the outputs + backward + torch.optim.Adam (unattended data parallelism attaches itself in forward)
+            # the outputs + backward + Adam.  The update is the library's fused Adam over the flat buckets (torch.optim.Adam's
+            # defaults, one launch; the gradients autograd left in p.grad are gathered into the flat buffer by one
+            # multi-tensor copy — and all-reduced there when there is more than one rank): torch.optim.Adam's foreach path
+            # costs this 900-parameter model ~250 small launches and 3.5 ms of GPU time per step (SCAT_BENCH_TORCH_ADAM=1)
             self.net = net
-            self.opt = torch.optim.Adam(net.parameters(), lr=1e-5)
+            if os.environ.get("SCAT_BENCH_TORCH_ADAM", "0") != "0":
+                self.opt = torch.optim.Adam(net.parameters(), lr=1e-5)
+            else:
+                from scat_amd.dp import GradBuckets
+                from scat_amd.trainer import FusedAdam
+                self.opt = FusedAdam(GradBuckets(net), lr=1e-5)
             self.cot = None
             self.ts = None
         else:
@@ -92,7 +100,10 @@ class Step:
         x = self.ops.preprocess_u8(u8, (224, 224))      # normalise + bilinear resize, one HIP kernel, in the step
         if self.ts is not None:
             return self.ts(x, lab)
-        self.opt.zero_grad(set_to_none=True)
+        if isinstance(self.opt, torch.optim.Optimizer):
+            self.opt.zero_grad(set_to_none=True)
+        else:
+            self.opt.zero_grad()
         pred = self.net(x)
         pred = pred[0] if isinstance(pred, tuple) else pred
         if self.cot is None:
