@@ -87,6 +87,7 @@ BNB_MIN_H = int(os.environ.get("SCAT_BNB_MIN_H", "28"))   # fold bn3 only where 
 BNB = os.environ.get("SCAT_BNB", "1") != "0"   # fold bn3's backward apply into conv3's gradient kernels
 SUBSAMPLE = os.environ.get("SCAT_SUBSAMPLE", "1") != "0"   # pack the input of the 1x1/stride-2 shortcuts (stride-1 kernels)
 SIDE_SHORTCUT = os.environ.get("SCAT_SIDE_SHORTCUT", "1") != "0"   # forward: the shortcut convolution beside conv1..conv3 (own stream)
+SIDE_DS_BN = os.environ.get("SCAT_SIDE_DS_BN", "1") != "0"   # the shortcut's BatchNorm backward beside the main data-gradient chain
 STEM_FUSED_BWD = os.environ.get("SCAT_STEM_FUSED_BWD", "1") != "0"   # max-pool backward inside bn1's backward (stem)
 SIDE_WGRAD = os.environ.get("SCAT_SIDE_WGRAD", "1") != "0"   # bench.py clears it for its serialized, per-kernel-timed step
 
@@ -250,6 +251,25 @@ def _block_backward(bc, rec, dcur):
         put(w3, wgrad(dc3, c2, w3, 1, 0, s2.scale, s2.shift, True))
         da2 = ops.conv2d_dgrad_w(dc3, w3, tuple(c2.shape), 1, 0, wp=wp)
         del dc3
+    ev_ds = dcd = None
+    if cd is not None and SIDE_DS_BN and bc.side is not None:
+        # The shortcut's BatchNorm backward needs only g: it runs on the idle fourth queue beside the conv3 -> conv2 -> conv1
+        # data-gradient chain (HBM-bound next to MFMA-bound kernels) instead of after it on the main stream.  Out of place:
+        # the chain is still reading g.
+        from .. import streams
+        aux = streams.get(g.device, "aux")
+        dsbn = blk.downsample[1]
+        dcd = torch.empty_like(cd)
+        dgs, dbs = gbuf(dsbn.weight), gbuf(dsbn.bias)
+        dgs = dgs if dgs is not None else torch.empty_like(dsbn.weight)
+        dbs = dbs if dbs is not None else torch.empty_like(dsbn.bias)
+        aux.wait_stream(bc.main)
+        with torch.cuda.stream(aux):
+            ops.bn_bwd(g, cd, None, False, sd.scale, sd.shift, sd.mean, sd.invstd, dsbn.weight, dgs, dbs, dx=dcd)
+            ev_ds = aux.record_event()
+        for tns in (g, cd, dcd, dgs, dbs):
+            tns.record_stream(aux)
+        put(dsbn.weight, dgs), put(dsbn.bias, dbs)
     dc2, dg, db = ops.bn_bwd(da2, c2, None, True, s2.scale, s2.shift, s2.mean, s2.invstd, blk.bn2.weight,
                              gbuf(blk.bn2.weight), gbuf(blk.bn2.bias), dx=da2)
     put(blk.bn2.weight, dg), put(blk.bn2.bias, db)
@@ -274,9 +294,12 @@ def _block_backward(bc, rec, dcur):
         bc.main.wait_event(ev3)      # the side stream's conv3 weight gradient has finished reading g
     if cd is not None:
         dsw, dsbn = blk.downsample[0].weight, blk.downsample[1]
-        dcd, dg, db = ops.bn_bwd(g, cd, None, False, sd.scale, sd.shift, sd.mean, sd.invstd, dsbn.weight,
-                                 gbuf(dsbn.weight), gbuf(dsbn.bias), dx=g)
-        put(dsbn.weight, dg), put(dsbn.bias, db)
+        if ev_ds is not None:
+            bc.main.wait_event(ev_ds)
+        else:
+            dcd, dg, db = ops.bn_bwd(g, cd, None, False, sd.scale, sd.shift, sd.mean, sd.invstd, dsbn.weight,
+                                     gbuf(dsbn.weight), gbuf(dsbn.bias), dx=g)
+            put(dsbn.weight, dg), put(dsbn.bias, db)
         if sd.xs is not None:
             put(dsw, wgrad(dcd, sd.xs, dsw, 1, 0))
         else:
