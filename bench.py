@@ -406,6 +406,30 @@ def main():
     # after everything that is timed): evidence that the queue plan held where the step actually ran
     from scat_amd import streams
     queue_mates = ["+".join((x, y)) + (" (one stream)" if why == "same stream" else "") for x, y, why in streams.sharing(dev)]
+    # data-parallel evidence, so that a scaling record can be audited for "did the collectives see N ranks, on which
+    # queues": per rank the queue-mates and what the queue-plan verification found; the backend, its version, whether
+    # ReduceOp.AVG is native, and the bytes of every gradient bucket
+    dp_info = None
+    buckets = step.ts.buckets if step.ts is not None else getattr(step.opt, "buckets", None)
+    if world > 1 or dist.is_initialized():
+        mine = {"rank": rank, "hw_queue_mates": queue_mates, "queue_plan": streams.plan_report(dev)}
+        per_rank = [None] * world
+        if world > 1:
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
+        backend = dist.get_backend()
+        ver = None
+        if backend == "nccl":
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:   # noqa: BLE001 - a missing version query must not cost the line
+                ver = None
+        dp_info = {"world": world, "backend": backend, "rccl_version": ver,
+                   "reduce_op_avg_native": bool(getattr(buckets, "_avg_ok", False)),
+                   "collectives_per_step": len(buckets.ranges) if buckets is not None else None,
+                   "bucket_bytes": ({b: 4 * (e - a0) for b, (a0, e) in buckets.ranges.items()} if buckets is not None else None),
+                   "per_rank": per_rank}
 
     if rank == 0:
         imgs = a.batch * world * a.steps
@@ -433,7 +457,7 @@ def main():
                                     "(error <= 2^-25 per product; DESIGN.md 3.0)" if lib().scat_get_math_mode() == 1
                                     else "fp32 MFMA"),
                        "whole_step_tflops_per_gpu": round(step_tf, 2), "pcie_inclusive": pcie,
-                       "hw_queue_mates": queue_mates},
+                       "hw_queue_mates": queue_mates, "data_parallel": dp_info},
             "roofline": roof, "roofline_hbm": roof_hbm, "cpu_baseline": cpu,
         }
         print(json.dumps(out), file=json_out, flush=True)

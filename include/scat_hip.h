@@ -100,6 +100,23 @@ int64_t scat_conv1x1_s1_ws(int M, int C);
 int scat_conv1x1_s1(const float* src, const float* w, float* dst, int B, int C, int HW, int M, int transposed,
                     const float* bias, const float* in_scale, const float* in_shift, int in_relu, int accumulate,
                     void* ws, int64_t ws_bytes, int w_ready, void* stream);
+/* ---- activations as pre-split bf16 planes ("P8" layout) ----
+ * The split-operand kernels form an fp32 product from the three bf16 terms hi + mid + lo of each operand; an activation
+ * tensor can be handed over already split:  planes[p][n][c / 8][pixel][c % 8]  (bf16; p = hi, mid, lo; C % 8 == 0;
+ * scat_planes_bytes(B, C, HW) bytes, 16-B aligned).  hi + mid + lo is exactly the fp32 value.
+ * scat_planes_from_f32: planes = split(relu?(src[B,C,HW] * scale + shift)) (scale / shift optional, per channel) — the
+ * fused BatchNorm + ReLU of models/resnet.py:85-86,89-90 applied once instead of in every consumer's operand load.
+ * scat_conv1x1_planes: scat_conv1x1_s1 with the activations given as planes (no input transform: it is already in
+ * them); the activation path is LDS-DMA only (buffer_load ... lds), bit-identical results.  C % 32 == 0.
+ * lds_stages: depth of the LDS ring the activations land in (2: 48 KB, three workgroups per CU; 3: 72 KB, two, one
+ * more stage in flight); 0 = the library's choice.
+ * Replaces nn.Conv2d(k=1) forward / input gradient at models/resnet.py:65-72,84-92. */
+int64_t scat_planes_bytes(int B, int C, int HW);
+int scat_planes_from_f32(const float* src, void* planes, int B, int C, int HW, const float* in_scale,
+                         const float* in_shift, int in_relu, void* stream);
+int scat_conv1x1_planes(const void* planes, const float* w, float* dst, int B, int C, int HW, int M, int transposed,
+                        const float* bias, int accumulate, void* ws, int64_t ws_bytes, int w_ready, int lds_stages,
+                        void* stream);
 /* ---- persistent stream-K schedule for the pointwise kernels ----
  * One tile per workgroup leaves the last round of a launch half empty at batch 96 (588 / 1 176 tiles of 128 x 128 on the
  * 768 workgroup slots of the chip).  scat_streamk_arm(buf, bytes) before a call of scat_conv1x1_s1 / scat_conv1x1_s1_bnb

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/scat_hip.h"
 
@@ -65,6 +66,26 @@ struct FastDiv {
 #endif
     }
 };
+
+// the reference of the shifted BatchNorm sums (OutDesc::stats_shift, gemm_engine.h): a non-finite one (a diverged step's batch mean) must
+// not poison every later sum — the epilogue and the finish (norm.hip bn_partials_fin_kernel) both read it through this
+__device__ __forceinline__ float finite_or_zero(float c) {
+    return (__float_as_uint(c) & 0x7f800000u) != 0x7f800000u ? c : 0.f;
+}
+
+// Tuning switches (tile targets, schedule variants whose losing side is a recorded negative result: DESIGN.md 1b / 1c)
+// exist only in the tools build.  In the shipped library the default is a constant: its dispatch depends on the shapes of a
+// call and on the five documented switches (SCAT_MATH, SCAT_PC, SCAT_WG_ROWS, SCAT_BN_LASTBLOCK, SCAT_BN_ONEPASS), which
+// the parity tests use to reach both sides of a dispatch.
+static inline long long diag_env_int(const char* name, long long dflt) {
+#ifdef SCAT_DIAG
+    const char* e = getenv(name);
+    return e ? atoll(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

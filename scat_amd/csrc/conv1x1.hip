@@ -1195,7 +1195,7 @@ __global__ void w1x1_t_kernel(const float* __restrict__ w, float* __restrict__ w
 }
 
 static int pw_plain_mode() {
-    static const int m = [] { const char* e = getenv("SCAT_PW_PLAIN"); return e ? atoi(e) : 1; }();
+    static const int m = diag_env_int("SCAT_PW_PLAIN", 1);
     return m;
 }
 
@@ -1220,7 +1220,7 @@ static bool sk_take(SkDesc& sk) {
     sk.id = g_sk_id.fetch_add(1, std::memory_order_relaxed);
     if (sk.id == 0) sk.id = g_sk_id.fetch_add(1, std::memory_order_relaxed);   // 0 is what a fresh buffer holds
     sk.G = SK_G;
-    static const int coh = [] { const char* e = getenv("SCAT_SK_COH"); return e ? atoi(e) : 1; }();
+    static const int coh = diag_env_int("SCAT_SK_COH", 1);
     sk.coh = coh;
     return true;
 }
@@ -1500,7 +1500,7 @@ extern "C" int scat_conv1x1_s1(const float* src, const float* w, float* dst, int
         d.w = (const float*)ws;
         d.nw = (nel * 6 + 3) / 4;
         if (!(tuning() >= 1 && tuning() <= 3)) {
-            static const int thin = [] { const char* e = getenv("SCAT_PW_THIN"); return e ? atoi(e) : 0; }();
+            static const int thin = diag_env_int("SCAT_PW_THIN", 0);
             cfg = M > 64 ? 0 : 1;   // measured at batch 96: 64x64 never wins
             if (cfg == 0 && tiles(128, 128) < thin) cfg = 1;          // (SCAT_PW_THIN: 64x128 below that many tiles)
         }

@@ -507,13 +507,13 @@ extern "C" int scat_conv3x3_s1(const float* src, const float* w, float* dst, int
     d.RS = bn + 2 * (W + 1);
     if (split) {
         if (!(tuning() >= 1 && tuning() <= 3)) {         // measured at batch 96: 64x128 unless the grid gets thin
-            static const int thin = [] { const char* e = getenv("SCAT_C3_THIN"); return e ? atoi(e) : 512; }();
+            static const int thin = diag_env_int("SCAT_C3_THIN", 512);
             cfg = tiles(64, 128) >= thin ? 1 : 2;
             d.RS = (cfg == 2 ? 64 : 128) + 2 * (W + 1);
         }
         // 32 output channels (HRNet's highest-resolution branch, models/hrnet.py:79-144): a 64-row tile would spend half
         // of its MFMAs on rows that do not exist — four wavefronts side by side on one 32-row block instead
-        static const int thin32 = [] { const char* e = getenv("SCAT_C3_M32"); return e ? atoi(e) : 1; }();
+        static const int thin32 = diag_env_int("SCAT_C3_M32", 1);
         if (Cdst <= 32 && thin32 && !(tuning() >= 1 && tuning() <= 3)) {
             d.RS = 128 + 2 * (W + 1);
             set_kernel_label("conv3x3_split_32x128x16%s%s", transposed ? "_dgrad" : "", in_scale ? "_tf" : "");

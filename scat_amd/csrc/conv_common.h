@@ -66,7 +66,7 @@ void wgrad_split_launch(const WgSplitPlan& p, const float* dy, const float* x, f
 // position in the run k % tg, v = (k / tg) * 8 + x.  ngroup = 1 (whole slices, grid padded to a multiple of 8 slices)
 // whenever there are many slices; 8 / gcd(8, splits) for the few-slice launches so that all eight XCDs get work.
 static inline int splitk_xcd_groups(int splits) {
-    static const int on = [] { const char* e = getenv("SCAT_WG_XCD"); return e ? atoi(e) : 1; }();
+    static const int on = diag_env_int("SCAT_WG_XCD", 1);
     if (!on) return 0;         // A/B switch: 0 = tiles in XCD chunks, slices in launch order (the round-2 mapping)
     if (splits >= 32 || splits % 8 == 0) return 1;
     int g = 8;

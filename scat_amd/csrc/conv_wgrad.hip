@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * WAVES) void splitk_reduce4_kernel(const float4
 }
 
 void launch_splitk_reduce(const float* slab, float* out, int64_t n, int splits, int accumulate, hipStream_t st) {
-    static const int vec = [] { const char* e = getenv("SCAT_REDUCE_VEC"); return e ? atoi(e) : 1; }();
+    static const int vec = diag_env_int("SCAT_REDUCE_VEC", 1);
     if (vec && n % 4 == 0 && (((uintptr_t)slab | (uintptr_t)out) & 15) == 0) {
         const int64_t n4 = n / 4;
         const dim3 grid((unsigned)((n4 + 63) / 64));
@@ -94,7 +94,7 @@ void launch_splitk_reduce(const float* slab, float* out, int64_t n, int splits, 
 
 static int wgrad_splits(int M, int N, int K, int bm, int bn) {
     int tiles = cdiv(M, bm) * cdiv(N, bn);
-    static const int target = [] { const char* e = getenv("SCAT_WG_F32_TARGET"); return e ? atoi(e) : 1024; }();
+    static const int target = diag_env_int("SCAT_WG_F32_TARGET", 1024);
     int s = cdiv(target, tiles);                     // aim for ~4 workgroups per CU
     int smax = K / 512 > 0 ? K / 512 : 1;            // keep >= 512 contraction steps per slice
     if (s > smax) s = smax;
@@ -148,7 +148,7 @@ static void wgrad_gemm(const WgradPlan& p, const GatherDesc& da, const GatherDes
 // on Cout*Cin*k*k below which the fp32 engine is used instead)
 static bool wgrad_split_ok(int KH, int stride, int pad, int Cout, int Cin) {
     // (1x1/stride 2: the strided 8-dword gather makes the split kernel staging-bound, 315-380 us vs 240-250 us)
-    static const int64_t minmn = [] { const char* e = getenv("SCAT_WG_MINMN"); return e ? atoll(e) : 0ll; }();
+    static const int64_t minmn = diag_env_int("SCAT_WG_MINMN", 0ll);
     return ((KH == 1 && pad == 0 && stride == 1) || (KH == 3 && pad == 1)) && (int64_t)Cout * Cin * KH * KH > minmn;
 }
 

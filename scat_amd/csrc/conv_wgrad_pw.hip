@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * (WA * WB + NP)) void wgrad_pw_kernel(WgPwDesc 
 }
 
 static int wg_pw_np() {        // SCAT_WGPW_NP=8: eight producer wavefronts with the eight-consumer tiles (1024 threads)
-    static const int m = [] { const char* e = getenv("SCAT_WGPW_NP"); return e ? atoi(e) : 4; }();
+    static const int m = diag_env_int("SCAT_WGPW_NP", 4);
     return m;
 }
 
@@ -381,7 +381,7 @@ static void launch_wg_pw_v(bool tf, bool rag, const WgPwDesc& d, const OutDesc& 
 }
 
 static int wg_pw_mode() {       // SCAT_WG_PW=0: the first-generation kernels everywhere (A/B runs)
-    static const int m = [] { const char* e = getenv("SCAT_WG_PW"); return e ? atoi(e) : 1; }();
+    static const int m = diag_env_int("SCAT_WG_PW", 1);
     return m;
 }
 
@@ -402,7 +402,7 @@ WgPwPlan wgrad_pw_plan(int B, int Cin, int Cout, int HW, bool dsa, const void* d
     const int NO = (HW + 7) / 8;
     p.stages = (B * NO + 3) / 4;
     const int tiles = cdiv(Cout, 64 * p.wa) * cdiv(Cin, 64 * p.wb);
-    static const int forced = [] { const char* e = getenv("SCAT_WGPW_TARGET"); return e ? atoi(e) : 0; }();
+    static const int forced = diag_env_int("SCAT_WGPW_TARGET", 0);
     const int target = forced > 0 ? forced : 256;      // one workgroup per CU
     int s = cdiv(target, tiles);
     const int smax = p.stages / 8 > 0 ? p.stages / 8 : 1;      // >= 8 stages (256 pixels) per slice

@@ -491,7 +491,7 @@ bool wgrad_rows_ok(int B, int Cin, int H, int W, int Cout, int KH, int stride, i
 static void rows_plan(int B, int Cin, int H, int W, int Cout, int& rpw, int& splits) {
     const bool big = W <= 32;                                 // 64 x 64 blocks
     const int rows = B * H, combos = big ? (Cin / 64) * (Cout / 64) : (Cin / 32) * (Cout / 32);
-    static const int tgt = [] { const char* e = getenv("SCAT_WG_ROWS_TARGET"); return e ? atoi(e) : 0; }();
+    static const int tgt = diag_env_int("SCAT_WG_ROWS_TARGET", 0);
     const int target = tgt > 0 ? tgt : 256;                   // one workgroup per CU (LDS)
     int s = (target + combos - 1) / combos;
     rpw = (rows + s - 1) / s;
@@ -541,7 +541,7 @@ int wgrad_rows_launch(const float* dy, const float* x, float* slab, int B, int C
     d.dH = FastDiv::make(H);
     d.ndy = (int64_t)B * Cout * H * W; d.nx = (int64_t)B * Cin * H * W;
     d.rpw = rpw;
-    static const int stamp = [] { const char* e = getenv("SCAT_WG_ROWS_STAMP"); return e ? atoi(e) : 0; }();
+    static const int stamp = diag_env_int("SCAT_WG_ROWS_STAMP", 0);
     d.stamp = kDiag ? stamp : 0;
     const size_t lds_bytes = (size_t)(4 * 3 + 2 * 9) * d.noct * 32 * 16;
     static bool once = (hipFuncSetAttribute((const void*)wgrad3x3_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -474,7 +474,7 @@ static void launch_wg_pc(const WgDesc& d, const OutDesc& dc, int splits, hipStre
 
 // SCAT_WG_PC=0: every wavefront stages and multiplies; 1: producer / consumer wavefronts for the 128 x 128 tiles
 static int wg_pc_mode() {
-    static const int m = [] { const char* e = getenv("SCAT_WG_PC"); return e ? atoi(e) : 1; }();
+    static const int m = diag_env_int("SCAT_WG_PC", 1);
     return m;
 }
 
@@ -508,13 +508,13 @@ WgSplitPlan wgrad_split_plan(int B, int Cin, int Cout, int KK, int HW) {
     // kernels share the GPU with the data-gradient chain): ~1.5 workgroups per CU for 1x1 (384), ~3 for 3x3 (768).  (Alone on the
     // GPU the 3x3 kernel prefers ~6 — its staging is VALU-bound and more co-resident waves help — but in the step
     // the extra slab traffic and reduce work cost more: 1536 -> 768 is +1.0 % on the step.)
-    static const int forced = [] { const char* e = getenv("SCAT_WG_TARGET"); return e ? atoi(e) : 0; }();
-    static const int forced1 = [] { const char* e = getenv("SCAT_WG_TARGET1"); return e ? atoi(e) : 0; }();
-    static const int forced9 = [] { const char* e = getenv("SCAT_WG_TARGET9"); return e ? atoi(e) : 0; }();
+    static const int forced = diag_env_int("SCAT_WG_TARGET", 0);
+    static const int forced1 = diag_env_int("SCAT_WG_TARGET1", 0);
+    static const int forced9 = diag_env_int("SCAT_WG_TARGET9", 0);
     const int f = KK == 1 ? (forced1 > 0 ? forced1 : forced) : (forced9 > 0 ? forced9 : forced);
     const int target = f > 0 ? f : (KK == 1 ? 384 : 768);
     int s = cdiv(target, tiles);
-    static const int minst = [] { const char* e = getenv("SCAT_WG_MINSTAGES"); return e ? atoi(e) : 24; }();
+    static const int minst = diag_env_int("SCAT_WG_MINSTAGES", 24);
     const int smax = p.stages / minst > 0 ? p.stages / minst : 1;   // >= 24 stages (384 pixels) per slice
     if (s > smax) s = smax;
     if (s > 2048) s = 2048;

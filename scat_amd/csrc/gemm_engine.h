@@ -488,7 +488,7 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[MI][NI], const OutDesc&
                 float cref = 0.f;
                 if (dc.stats_shift) {
                     const int ir = ibase + a * 32 + (r & 3) + 8 * (r >> 2);
-                    cref = dc.stats_shift[ir < M ? ir : 0];
+                    cref = finite_or_zero(dc.stats_shift[ir < M ? ir : 0]);
                 }
                 float ss = 0.f, qq = 0.f;
 #pragma unroll

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void gemm_group_reduce_kernel(GroupArgs g) {
 // rows of a tile: 64.  (128-row tiles — twice the MFMAs per staged B element, half the tiles — measured 3 % slower on
 // the token mixer's twelve problems at batch 96, tools/vit_group_bench.py; SCAT_GROUP_BM=128 for A/B runs.)
 static int group_bm(const ScatGemmProblem*, int) {
-    static const int forced = [] { const char* e = getenv("SCAT_GROUP_BM"); return e ? atoi(e) : 0; }();
+    static const int forced = diag_env_int("SCAT_GROUP_BM", 0);
     return forced == 128 ? 128 : 64;
 }
 

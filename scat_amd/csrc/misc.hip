@@ -54,7 +54,7 @@ int math_mode() {
 }
 
 int tuning() {
-    static int v = [] { const char* e = getenv("SCAT_TUNE"); return e ? atoi(e) : 0; }();
+    static int v = diag_env_int("SCAT_TUNE", 0);
     return v;
 }
 

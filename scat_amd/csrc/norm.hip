@@ -111,7 +111,7 @@ struct BnFin {                // what a last arriver needs to finish a channel (
 static inline int ew_grid(int64_t n) { return (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384); }
 
 static int bn_splits(int B, int C) {
-    static const int target = [] { const char* e = getenv("SCAT_BN_BLOCKS"); return e ? atoi(e) : 2048; }();
+    static const int target = diag_env_int("SCAT_BN_BLOCKS", 2048);
     int s = cdiv(target, C);
     if (s > B) s = B;
     if (s > 256) s = 256;      // (one thread per slot in bn_publish)
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void bn_partials_fin_kernel(const float* __res
     if (threadIdx.x == 0) {
         if (stat_shift) {
             const double d1 = s1 / count;
-            bn_finish_mv(c, (double)stat_shift[c] + d1, s2 / count - d1 * d1, count, gamma, beta, rmean, rvar, momentum, eps,
+            bn_finish_mv(c, (double)finite_or_zero(stat_shift[c]) + d1, s2 / count - d1 * d1, count, gamma, beta, rmean, rvar, momentum, eps,
                          save_mean, save_invstd, scale, shift);
         } else {
             bn_finish(c, s1, s2, count, gamma, beta, rmean, rvar, momentum, eps, save_mean, save_invstd, scale, shift);
@@ -911,7 +911,7 @@ extern "C" int scat_bn_train_stats(const float* x, int B, int C, int HW, const f
     SCAT_REQUIRE(ws && ws_bytes >= scat_bn_ws(B, C, HW), SCAT_E_WORKSPACE, "scat_bn_train_stats: workspace too small");
     const int S = bn_splits(B, C);
     hipStream_t st = (hipStream_t)stream;
-    static const int fused_min_c = [] { const char* e = getenv("SCAT_BN_FUSED_MIN_C"); return e ? atoi(e) : 256; }();
+    static const int fused_min_c = diag_env_int("SCAT_BN_FUSED_MIN_C", 256);
     if (C >= fused_min_c) {
         const double count = (double)B * HW;
         if ((HW & 3) == 0 && ((uintptr_t)x & 15) == 0)
@@ -1032,7 +1032,7 @@ extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, 
                      (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y_out | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
     SCAT_REQUIRE(!y_mask || vec, SCAT_E_SHAPE, "scat_bn_bwd: the sign mask needs HW % 4 == 0 and 16-B aligned tensors");
     SCAT_REQUIRE(!(y_mask && y_out), SCAT_E_ARG, "scat_bn_bwd: pass the output OR its sign mask");
-    static const int fused_min_c = [] { const char* e = getenv("SCAT_BN_FUSED_MIN_C"); return e ? atoi(e) : 256; }();
+    static const int fused_min_c = diag_env_int("SCAT_BN_FUSED_MIN_C", 256);
     // small planes: one workgroup per channel holds its elements in registers (reduce + apply in one launch)
     static const int onepass = [] { const char* e = getenv("SCAT_BN_ONEPASS"); return e ? atoi(e) : 1; }();
     const int64_t nvc = (int64_t)B * HW / (vec ? 4 : 1);

@@ -43,8 +43,10 @@ def _force_collectives():
 # The host driver of this pool only supports dmabuf IPC: RCCL's peer mappings over xGMI fail with "hipIpcGetMemHandle:
 # invalid argument" without this, and it has to be in the environment BEFORE HIP initialises — i.e. before the model's
 # constructor calls .cuda() (hand_net.py:321), which in the unattended path (auto_attach, from the first forward) is long
-# past.  Importing the package is the earliest point this library controls.
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# past.  Importing the package is the earliest point this library controls.  Only multi-process runs need it (a launcher
+# has set WORLD_SIZE, or the one-rank collective test forces the path): a single-GPU user's environment is left alone.
+if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or _force_collectives():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 _PRODUCERS: List = []   # streams other than the caller's on which gradient kernels run (process-wide)
 
@@ -396,6 +398,10 @@ def init_distributed():
             from . import streams     # hardware queues: the train step's streams are bound before RCCL's (streams.py)
             streams.plan_for_collectives(torch.device("cuda", local))
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        if torch.cuda.is_available() and backend == "nccl":
+            # the queue plan is verified, not trusted: did the communicator take the stream left for it, and do the
+            # step's heavy streams still sit on queues of their own (re-picked / warned about otherwise)
+            streams.verify_collective_plan(torch.device("cuda", local))
     return rank, local, world
 
 

@@ -19,6 +19,8 @@ import warnings
 
 import numpy as np
 import torch
+
+from .. import _switches as _sw
 import torch.nn as nn
 
 from .. import nn as snn
@@ -55,11 +57,24 @@ _ONES = {}
 
 
 def _ones_like(t):
-    """a cached all-ones tensor (the cotangent of ``sum(feat_out)``, hand_net.py:396): one fill per shape, not per step"""
+    """a cached all-ones tensor (the cotangent of ``sum(feat_out)``, hand_net.py:396): one fill per shape, not per step.
+    The fill runs on whichever stream is current at first use; a reader on ANOTHER stream (a second model in the process,
+    SCAT_OVERLAP_TOKENS=0) waits for the event recorded behind it.  Read-only by contract: it is only ever handed to
+    Transformer.input_grad as ``dy`` (never an ``out=`` target)."""
     key = (tuple(t.shape), t.dtype, str(t.device))
-    o = _ONES.get(key)
-    if o is None:
-        o = _ONES[key] = torch.ones_like(t)
+    e = _ONES.get(key)
+    if e is None:
+        o = torch.ones_like(t)
+        ev = st = None
+        if o.is_cuda:
+            st = torch.cuda.current_stream(o.device)
+            ev = st.record_event()
+        e = _ONES[key] = (o, ev, st)
+    o, ev, st = e
+    if ev is not None:
+        cur = torch.cuda.current_stream(o.device)
+        if cur != st:
+            cur.wait_event(ev)       # (a completed event costs nothing on the device)
     return o
 
 
@@ -74,9 +89,9 @@ def _upload_indices(idx, device):
     return h.pin_memory().to(device, non_blocking=True)
 
 
-OVERLAP_TOKENS = os.environ.get("SCAT_OVERLAP_TOKENS", "1") != "0"   # token path next to layer3/layer4 (own stream)
-TOKENS_FIRST_IN_BACKWARD = os.environ.get("SCAT_TOKENS_FIRST", "1") != "0"   # (0: the round-2 node order, for A/B runs)
-TOKEN_PRIO = os.environ.get("SCAT_TOKEN_PRIO", "0") != "0"   # token stream with high priority (A/B switch)
+OVERLAP_TOKENS = _sw.ab("SCAT_OVERLAP_TOKENS", True)   # token path next to layer3/layer4 (own stream)
+TOKENS_FIRST_IN_BACKWARD = _sw.ab("SCAT_TOKENS_FIRST", True)   # (0: the round-2 node order, for A/B runs)
+TOKEN_PRIO = _sw.ab("SCAT_TOKEN_PRIO", False)   # token stream with high priority (A/B switch)
 # The token-path parameters get their gradients from nodes that ran on the token stream while their AccumulateGrad
 # nodes belong to the caller's stream: autograd orders the two (that is the design) and says so once per process.
 warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")

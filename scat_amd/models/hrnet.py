@@ -12,6 +12,8 @@ inplanes == planes wherever it is used.
 from __future__ import annotations
 
 import torch
+
+from .. import _switches as _sw
 import torch.nn as nn
 
 from .. import nn as snn
@@ -84,13 +86,16 @@ class _CbrFn(torch.autograd.Function):
             torch._foreach_add_(_rn._NBT, 1)
             _rn._NBT.clear()
         out = ops.bn_apply(c, s.scale, s.shift, None, True)
-        if training and any(ctx.needs_input_grad):
+        ctx.rec = training and any(ctx.needs_input_grad)
+        if ctx.rec:
             ctx.conv, ctx.bn, ctx.s = conv, bn, s
             ctx.save_for_backward(x, c)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        if not ctx.rec:     # (callers take the per-layer path for an eval-mode BatchNorm under grad: _fused_ok)
+            raise RuntimeError("scat_amd: conv+BatchNorm+ReLU backward needs a training-mode forward (BN batch statistics)")
         x, c = ctx.saved_tensors
         conv, bn, s = ctx.conv, ctx.bn, ctx.s
         st, pd = conv.stride[0], conv.padding[0]
@@ -131,13 +136,16 @@ class _FuseSumFn(torch.autograd.Function):
             torch._foreach_add_(_rn._NBT, 1)
             _rn._NBT.clear()
         out = ops.fuse_sum(terms, relu=True)
-        if training and any(ctx.needs_input_grad):
+        ctx.rec = training and any(ctx.needs_input_grad)
+        if ctx.rec:
             ctx.spec, ctx.states = spec, states
             ctx.save_for_backward(out, *tens)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        if not ctx.rec:
+            raise RuntimeError("scat_amd: exchange-unit backward needs a training-mode forward (BN batch statistics)")
         out, *tens = ctx.saved_tensors
         spec, states = ctx.spec, ctx.states
         n = len(spec)
@@ -157,11 +165,18 @@ class _FuseSumFn(torch.autograd.Function):
         return (None, *grads, *pgrads)
 
 
+def _fused_ok(*bns):
+    """The fused nodes keep what their backward needs only in training mode (batch statistics).  A backward through an
+    eval-mode BatchNorm (frozen-BN fine-tuning, saliency maps) is legal for nn.BatchNorm2d, so those calls take the
+    per-layer autograd path instead."""
+    return not torch.is_grad_enabled() or all(bn.training for bn in bns)
+
+
 class _CBR(nn.Sequential):
     """nn.Sequential(Conv2d, BatchNorm2d, ReLU) with the reference's state_dict keys, executed as one node"""
 
     def forward(self, x):
-        if FUSED_CBR and x.is_cuda and self[0].bias is None:
+        if FUSED_CBR and x.is_cuda and self[0].bias is None and _fused_ok(self[1]):
             return _CbrFn.apply(x, self[0], self[1], self[0].weight, self[1].weight, self[1].bias)
         return super().forward(x)
 
@@ -172,13 +187,13 @@ _DEFER_NBT = [False]     # set by HRNet.forward: the blocks leave their num_batc
 
 # BatchNorm sums in the convolution epilogue: measured a wash on these short contractions (K = 288 .. 2304 with the
 # statistics passes already hidden on the branch streams: 70.0 vs 69.0 ms / step), so off here; ResNet-50: +1.8 %
-EPI_STATS = os.environ.get("SCAT_HRNET_EPI", "0") != "0"
-FUSED_BASIC = os.environ.get("SCAT_HRNET_FUSED", "1") != "0"   # 0: the per-layer autograd path, for A/B runs
-FUSED_EXCHANGE = os.environ.get("SCAT_HRNET_FUSED_X", "1") != "0"   # an exchange output's BatchNorms, upsamples, adds and ReLU: one node
-FUSED_CBR = os.environ.get("SCAT_HRNET_FUSED_CBR", "1") != "0"   # conv + BatchNorm + ReLU units as one node each
-EPI_STATS_CBR = os.environ.get("SCAT_HRNET_CBR_EPI", "1") != "0"   # ... with the BatchNorm sums from the convolution epilogue
-FUSED_BOTTLENECK = os.environ.get("SCAT_HRNET_FUSED_L1", "1") != "0"   # layer1's Bottlenecks on ResNet's block executor
-PARALLEL_BRANCHES = os.environ.get("SCAT_HRNET_PAR", "1") != "0"   # one stream per resolution branch of a stage
+EPI_STATS = _sw.ab("SCAT_HRNET_EPI", False)
+FUSED_BASIC = _sw.ab("SCAT_HRNET_FUSED", True)   # 0: the per-layer autograd path, for A/B runs
+FUSED_EXCHANGE = _sw.ab("SCAT_HRNET_FUSED_X", True)   # an exchange output's BatchNorms, upsamples, adds and ReLU: one node
+FUSED_CBR = _sw.ab("SCAT_HRNET_FUSED_CBR", True)   # conv + BatchNorm + ReLU units as one node each
+EPI_STATS_CBR = _sw.ab("SCAT_HRNET_CBR_EPI", True)   # ... with the BatchNorm sums from the convolution epilogue
+FUSED_BOTTLENECK = _sw.ab("SCAT_HRNET_FUSED_L1", True)   # layer1's Bottlenecks on ResNet's block executor
+PARALLEL_BRANCHES = _sw.ab("SCAT_HRNET_PAR", True)   # one stream per resolution branch of a stage
 
 
 def _branch_stream(device, i):
@@ -273,7 +288,8 @@ class StageModule(nn.Module):
         self.relu = snn.ReLU(inplace=True)
 
     def _fuse(self, i, x):
-        if FUSED_EXCHANGE and x[0].is_cuda and len(self.branches) <= 4:
+        if (FUSED_EXCHANGE and x[0].is_cuda and len(self.branches) <= 4
+                and _fused_ok(*[m for m in self.fuse_layers[i].modules() if isinstance(m, nn.BatchNorm2d)])):
             # the convolutions stay nodes of their own; everything after the last one of each term is one node
             spec, tens, params = [], [], []
             for j in range(len(self.branches)):
@@ -380,7 +396,7 @@ class HRNet(nn.Module):
 
     def _forward(self, x):
         self._wprep.run(self.training)
-        if FUSED_CBR and x.is_cuda:
+        if FUSED_CBR and x.is_cuda and _fused_ok(self.bn1, self.bn2):
             x = _CbrFn.apply(x, self.conv1, self.bn1, self.conv1.weight, self.bn1.weight, self.bn1.bias)
             x = _CbrFn.apply(x, self.conv2, self.bn2, self.conv2.weight, self.bn2.weight, self.bn2.bias)
         else:

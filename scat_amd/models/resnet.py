@@ -19,6 +19,8 @@ from __future__ import annotations
 import os
 
 import torch
+
+from .. import _switches as _sw
 import torch.nn as nn
 
 from .. import nn as snn
@@ -81,15 +83,15 @@ class _BNState:
             self.mean = self.invstd = None
 
 
-BNB1 = os.environ.get("SCAT_BNB1", "0") != "0"   # same for bn1 -> conv1: measured slower (its passes hide under the side stream), off
-BNB1_MIN_H = int(os.environ.get("SCAT_BNB1_MIN_H", "0"))
-BNB_MIN_H = int(os.environ.get("SCAT_BNB_MIN_H", "28"))   # fold bn3 only where it pays: 56x56 and 28x28 planes (tools/bnb_bench.py: at 14x14 the dual-source kernels cost more than the pass they save)
-BNB = os.environ.get("SCAT_BNB", "1") != "0"   # fold bn3's backward apply into conv3's gradient kernels
-SUBSAMPLE = os.environ.get("SCAT_SUBSAMPLE", "1") != "0"   # pack the input of the 1x1/stride-2 shortcuts (stride-1 kernels)
-SIDE_SHORTCUT = os.environ.get("SCAT_SIDE_SHORTCUT", "1") != "0"   # forward: the shortcut convolution beside conv1..conv3 (own stream)
-SIDE_DS_BN = os.environ.get("SCAT_SIDE_DS_BN", "1") != "0"   # the shortcut's BatchNorm backward beside the main data-gradient chain
-STEM_FUSED_BWD = os.environ.get("SCAT_STEM_FUSED_BWD", "1") != "0"   # max-pool backward inside bn1's backward (stem)
-SIDE_WGRAD = os.environ.get("SCAT_SIDE_WGRAD", "1") != "0"   # bench.py clears it for its serialized, per-kernel-timed step
+BNB1 = _sw.ab("SCAT_BNB1", False)   # same for bn1 -> conv1: measured slower (its passes hide under the side stream), off
+BNB1_MIN_H = _sw.ab_int("SCAT_BNB1_MIN_H", 0)
+BNB_MIN_H = _sw.ab_int("SCAT_BNB_MIN_H", 28)   # fold bn3 only where it pays: 56x56 and 28x28 planes (tools/bnb_bench.py: at 14x14 the dual-source kernels cost more than the pass they save)
+BNB = _sw.ab("SCAT_BNB", True)   # fold bn3's backward apply into conv3's gradient kernels
+SUBSAMPLE = _sw.ab("SCAT_SUBSAMPLE", True)   # pack the input of the 1x1/stride-2 shortcuts (stride-1 kernels)
+SIDE_SHORTCUT = _sw.ab("SCAT_SIDE_SHORTCUT", True)   # forward: the shortcut convolution beside conv1..conv3 (own stream)
+SIDE_DS_BN = _sw.ab("SCAT_SIDE_DS_BN", True)   # the shortcut's BatchNorm backward beside the main data-gradient chain
+STEM_FUSED_BWD = _sw.ab("SCAT_STEM_FUSED_BWD", True)   # max-pool backward inside bn1's backward (stem)
+SIDE_WGRAD = _sw.ab("SCAT_SIDE_WGRAD", True)   # bench.py clears it for its serialized, per-kernel-timed step
 
 
 def _side_stream(device, who="backbone"):
@@ -101,7 +103,7 @@ def _side_stream(device, who="backbone"):
     return streams.get(device, "wgrad" if who == "backbone" else "tokens_wgrad")
 
 
-STAT_REF = os.environ.get("SCAT_STAT_REF", "1") != "0"   # epilogue BatchNorm sums about the previous step's batch mean
+STAT_REF = _sw.ab("SCAT_STAT_REF", True)   # epilogue BatchNorm sums about the previous step's batch mean
 
 
 def _ref(bn):
@@ -481,7 +483,7 @@ class _BackboneFn(torch.autograd.Function):
                         ext = [f for f in ext if f is not e]
                         break
                 if (dcur is not None and len(ext) == 1 and ext[0].is_contiguous() and ext[0].data_ptr() % 16 == 0
-                        and os.environ.get("SCAT_DX2_FOLD", "1") != "0"):
+                        and _sw.ab("SCAT_DX2_FOLD", True)):
                     pending[0] = ext[0]        # summed by the first BatchNorm-backward reduction on its way in
                     return dcur
                 for e in ext:

@@ -184,6 +184,18 @@ class LayerNorm(nn.LayerNorm):
 class BatchNorm2d(nn.BatchNorm2d):
     fuse_relu = False
 
+    # ``_stat_ref`` (models/resnet.py _BNState): the previous training step's batch mean, the reference the convolution
+    # epilogue takes its BatchNorm sums about.  It is step-to-step scratch, not state: dropped whenever the step sequence
+    # is broken (a checkpoint is loaded, the module leaves training mode), so a resumed run starts like a fresh one.
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.__dict__.pop("_stat_ref", None)
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def train(self, mode=True):
+        if not mode:
+            self.__dict__.pop("_stat_ref", None)
+        return super().train(mode)
+
     def forward(self, x):
         if self.training and self.track_running_stats:
             self.num_batches_tracked += 1

@@ -11,6 +11,8 @@ import os
 
 import torch
 
+from . import _switches as _sw
+
 from ._lib import ScatError, lib
 
 _ws_cache = {}
@@ -89,7 +91,7 @@ BN_ONEPASS = os.environ.get("SCAT_BN_ONEPASS", "1") != "0"   # (the switch is re
 
 # kinds of scat_wprep_jobs (include/scat_hip.h SCAT_WPREP_*)
 WPREP_CONV1X1_FWD, WPREP_CONV1X1_DGRAD, WPREP_CONV3X3_FWD, WPREP_CONV3X3_DGRAD, WPREP_FWD_SPLIT, WPREP_DGRAD_S2 = range(6)
-WPREP = os.environ.get("SCAT_WPREP", "1") != "0"   # 0: every convolution re-lays its weights itself (A/B runs)
+WPREP = _sw.ab("SCAT_WPREP", True)   # 0: every convolution re-lays its weights itself (A/B runs)
 
 
 class WeightPrep:
@@ -213,16 +215,16 @@ def conv_out_hw(H, W, k, stride, pad):
     return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
 
 
-STEM_SPLIT = os.environ.get("SCAT_STEM_SPLIT", "1") != "0"   # the 7x7/s2 stem on split-operand products (0: fp32 engine)
-HALO = os.environ.get("SCAT_HALO", "1") != "0"   # 3x3/s1/p1 through the LDS-halo kernel (0: generic gather, for A/B runs)
+STEM_SPLIT = _sw.ab("SCAT_STEM_SPLIT", True)   # the 7x7/s2 stem on split-operand products (0: fp32 engine)
+HALO = _sw.ab("SCAT_HALO", True)   # 3x3/s1/p1 through the LDS-halo kernel (0: generic gather, for A/B runs)
 
 
 def _halo_ok(KH, KW, stride, pad, csrc, W):
     return HALO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and W <= 63
 
 
-PW_MIN_C = int(os.environ.get("SCAT_PW_MIN_C", "512"))
-PW = os.environ.get("SCAT_PW", "1") != "0"       # 1x1/s1 through the weights-in-registers kernel (0: generic gather)
+PW_MIN_C = _sw.ab_int("SCAT_PW_MIN_C", 512)
+PW = _sw.ab("SCAT_PW", True)       # 1x1/s1 through the weights-in-registers kernel (0: generic gather)
 
 
 def _pw_ok(KH, KW, stride, pad, csrc, *ts):
@@ -259,7 +261,7 @@ def streamk_check():
         lib().scat_streamk_error(_p(buf), buf.numel(), st)
 
 
-EPI_STATS = os.environ.get("SCAT_EPI_STATS", "1") != "0"   # BatchNorm sums in the convolution epilogue (0: separate pass)
+EPI_STATS = _sw.ab("SCAT_EPI_STATS", True)   # BatchNorm sums in the convolution epilogue (0: separate pass)
 
 
 def conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, bias=None, out=None, wp=None,
@@ -312,7 +314,7 @@ def _conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, 
               _p(bias), _p(in_scale), _p(in_shift), int(in_relu), 0, _p(ws), ws.numel(), rdy, _stream())
         return y
     if (stride == 2 and KH in (1, 3) and KW == KH and Cin % 16 == 0 and lib().scat_get_math_mode() == 1
-            and os.environ.get("SCAT_S2_SPLIT", "1") != "0"):
+            and _sw.ab("SCAT_S2_SPLIT", True)):
         ws, rdy = _wp_ws(wp, w, WPREP_FWD_SPLIT, Cout, Cin, KH, KW, pad,
                          lib().scat_conv2d_fwd_split_ws(Cout, Cin, KH, KW), x.device)
         _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_fwd_split, _p(x), _p(w), _p(bias), _p(y), B,
@@ -332,6 +334,61 @@ def _conv2d_fwd(x, w, stride, pad, in_scale=None, in_shift=None, in_relu=False, 
         return y
     _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_fwd, _p(x), _p(w), _p(bias), _p(y), B, Cin, H, W,
           Cout, KH, KW, stride, pad, _p(in_scale), _p(in_shift), int(in_relu), _stream())
+    return y
+
+
+# ---------------------------------------------------------------- activations as pre-split bf16 planes
+class Planes:
+    """An activation tensor [B, C, H, W] held as its three bf16 terms in the P8 layout (include/scat_hip.h:
+    planes[p][n][c / 8][pixel][c % 8]); ``buf`` is the caller-owned uint8 storage."""
+    __slots__ = ("buf", "shape")
+
+    def __init__(self, buf, shape):
+        self.buf, self.shape = buf, tuple(shape)
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def record_stream(self, s):
+        self.buf.record_stream(s)
+
+    def to_f32(self):
+        """hi + mid + lo as an fp32 NCHW tensor (exact) — tests and debugging only, plain torch"""
+        B, C, H, W = self.shape
+        v = self.buf.view(torch.bfloat16).view(3, B, C // 8, H * W, 8).float()
+        x = (v[2] + v[1]) + v[0]
+        return x.permute(0, 1, 3, 2).reshape(B, C, H, W).contiguous()
+
+
+def planes_from(x, scale=None, shift=None, relu=False, out=None):
+    """split(relu?(x * scale + shift)) -> Planes: one HBM-bound pass (4 B read, 6 B written per element)"""
+    _chk(x, scale, shift)
+    B, C, H, W = x.shape
+    nbytes = int(lib().scat_planes_bytes(B, C, H * W))
+    buf = out if out is not None else torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    _prof_hbm("planes_from_f32", 10.0 * x.numel(), lib().scat_planes_from_f32, _p(x), _p(buf), B, C, H * W, _p(scale),
+              _p(shift), int(relu), _stream())
+    return Planes(buf, (B, C, H, W))
+
+
+def _planes_ok(C, *ts):
+    return (lib().scat_get_math_mode() == 1 and C % 32 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in ts))
+
+
+def conv1x1_planes(xp, w, transposed=False, bias=None, out=None, accumulate=False, wp=None, lds_stages=0):
+    """scat_conv1x1_s1 with the activations given as Planes: forward (w = [Cout, Cin, 1, 1], xp has Cin channels) or,
+    transposed, the data gradient (xp = planes of dy with Cout channels -> dx with Cin channels)"""
+    _chk(w, bias, out)
+    B, C, H, W = xp.shape
+    Cout, Cin = w.shape[0], w.shape[1]
+    M = Cin if transposed else Cout
+    assert C == (Cout if transposed else Cin), (xp.shape, tuple(w.shape), transposed)
+    y = out if out is not None else torch.empty((B, M, H, W), dtype=torch.float32, device=w.device)
+    ws, rdy = _wp_ws(wp, w, WPREP_CONV1X1_DGRAD if transposed else WPREP_CONV1X1_FWD, Cout, Cin, 1, 1, 0,
+                     lib().scat_conv1x1_s1_ws(M, C), w.device)
+    _prof(2.0 * B * H * W * Cout * Cin, lib().scat_conv1x1_planes, _p(xp.buf), _p(w), _p(y), B, C, H * W, M,
+          int(transposed), _p(bias), int(accumulate), _p(ws), ws.numel(), rdy, int(lds_stages), _stream())
     return y
 
 
@@ -422,11 +479,11 @@ def gemm(a, a_si, a_sk, b, b_sk, b_sj, c, c_si, c_sj, M, N, K, bias=None, bias_m
     return c
 
 
-GEMM_SPLIT = os.environ.get("SCAT_GEMM_SPLIT", "1") != "0"        # dense projections on split-operand products
+GEMM_SPLIT = _sw.ab("SCAT_GEMM_SPLIT", True)        # dense projections on split-operand products
 # M*N*K below which the fp32 engine stays: measured (tools/vit_gemm_bench.py, M = 2016 tokens) the split kernel wins only
 # on the largest projection (qkv of layer 0, 2016 x 1536 x 784: 59 vs 72 us); the smaller ones are occupancy-bound
 # (49..768 workgroups on 256 CUs) and lose to the fp32 engine's split-K + 16-channel stages
-GEMM_SPLIT_MIN = int(os.environ.get("SCAT_GEMM_SPLIT_MIN", str(1 << 31)))
+GEMM_SPLIT_MIN = _sw.ab_int("SCAT_GEMM_SPLIT_MIN", 1 << 31)
 
 
 def _gemm_split_ok(M, N, K):
@@ -485,7 +542,7 @@ class _GemmProblem(ctypes.Structure):
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int)]
 
 
-GROUP_WGRAD = os.environ.get("SCAT_GROUP_WGRAD", "1") != "0"   # the token mixer's weight gradients as one launch
+GROUP_WGRAD = _sw.ab("SCAT_GROUP_WGRAD", True)   # the token mixer's weight gradients as one launch
 GROUP_MAX = 16
 
 
@@ -750,7 +807,7 @@ def attention_fwd(qkv, heads, dim_head, scale):
 # against 74 / 51 / 36 us for the two launches it replaces — 256 workgroups of three 21-token images each stream their
 # head's weight slice at the per-CU L2 fetch rate (~25 GB/s: 2.2 us per 32-feature stage for 0.6 us of MFMA), and the
 # step time does not move (the token path hides under layer3/layer4).
-VIT_FUSED = os.environ.get("SCAT_VIT_FUSED", "0") != "0"
+VIT_FUSED = _sw.ab("SCAT_VIT_FUSED", False)
 
 
 def vit_fused_ok(n, dim, dim_head):

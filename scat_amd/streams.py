@@ -27,7 +27,9 @@ import os
 
 import torch
 
-PROBE = os.environ.get("SCAT_STREAMS_PROBE", "1") != "0"   # 0: take pool streams as they come (A/B runs)
+from . import _switches as _sw
+
+PROBE = _sw.ab("SCAT_STREAMS_PROBE", True)   # 0: take pool streams as they come (A/B runs)
 
 _BOUND = {}          # device index -> {role: stream}
 ORDER = ("wgrad", "tokens", "comm", "tokens_wgrad", "aux", "opt")
@@ -63,6 +65,7 @@ def _finish_times(x, y):
 
 
 _ONE = {}
+_RETRIES = 4
 
 
 def _shares(a, b):
@@ -75,8 +78,9 @@ def _shares(a, b):
         _ONE[key] = min(_finish_times(a, a) for _ in range(3)) / 2
     # two streams on one queue can never finish both spins in one spin's time, so a single fast measurement proves they
     # run side by side; a slow one may be a clock ramp or a busy host: ask again (the minimum decides)
+    # (every "shares" verdict is therefore a minimum over _RETRIES + 1 measurements, every "independent" one a proof)
     t = _finish_times(a, b)
-    for _ in range(2):
+    for _ in range(_RETRIES):
         if t <= 1.35 * _ONE[key]:
             break
         t = min(t, _finish_times(a, b))
@@ -161,6 +165,77 @@ def plan_for_collectives(device):
         torch.cuda.Stream(device=device)
     b["_collective"] = ring[j]
     b["opt"] = b["comm"]
+    _PLAN[device.index] = {"ring": ring, "j": j, "verified": None}
+
+
+_PLAN = {}
+
+
+def verify_collective_plan(device):
+    """Call right AFTER the process group exists (scat_amd.dp.init_distributed does).  plan_for_collectives() relies on
+    two things torch does not document: its stream pool is handed out round-robin, and ProcessGroupNCCL draws exactly
+    one stream from it when its communicator comes up.  Both are CHECKED here instead of trusted: the next pool stream
+    must be the successor of the one the plan left for the collectives (else something else drew from the pool, or the
+    communicator was not created eagerly); and the heavy roles of the step — main, wgrad, tokens, comm and the
+    collective stream — are measured pairwise once more; a role that shares a queue with another is re-picked (nothing
+    has captured these streams yet at this point) and, if that does not help, named in a loud warning.
+    -> {"pool_walk_ok": bool | None, "shared": [pairs still sharing], "repicked": [roles]}; also kept for bench.py."""
+    import warnings
+
+    device = _dev(device)
+    b = bound(device)
+    plan = _PLAN.get(device.index)
+    res = {"pool_walk_ok": None, "shared": [], "repicked": []}
+    if plan is not None:
+        nxt = torch.cuda.Stream(device=device)
+        want = plan["ring"][(plan["j"] + 1) % 32]
+        res["pool_walk_ok"] = bool(nxt.cuda_stream == want.cuda_stream)
+        if not res["pool_walk_ok"]:
+            warnings.warn("scat_amd.streams: the process group did not take the pool stream the queue plan left for it "
+                          "(torch's stream pool is not where plan_for_collectives() expected it): the collectives may "
+                          "share a hardware queue with the train step — see config.hw_queues in the bench line",
+                          RuntimeWarning)
+    heavy = [n for n in ("wgrad", "tokens", "comm", "_collective") if n in b]
+
+    def clashes():
+        names = ["main"] + heavy
+        sts = [_main(device)] + [b[n] for n in heavy]
+        return [(names[i], names[k]) for i in range(len(sts)) for k in range(i + 1, len(sts))
+                if _shares(sts[i], sts[k])]
+
+    bad = clashes()
+    for _ in range(2):
+        movable = sorted({y for _, y in bad if y != "_collective"} | {x for x, y in bad if y == "_collective" and x != "main"})
+        if not movable:
+            break
+        from . import dp
+        for r in movable:
+            old = b.pop(r)
+            dp._PRODUCERS[:] = [s for s in dp._PRODUCERS if s is not old]
+            if b.get("opt") is old:
+                b.pop("opt")
+            names = tuple(n for n in ("main", "wgrad", "tokens", "comm", "_collective") if n != r)
+            b[r] = _pick(device, [_main(device) if n == "main" else b[n] for n in names if n == "main" or n in b])
+            if r in ("wgrad", "tokens"):
+                dp.register_producer(b[r])
+            if r == "comm":
+                b["opt"] = b[r]
+            res["repicked"].append(r)
+        bad = clashes()
+    res["shared"] = ["+".join(p) for p in bad]
+    if bad:
+        warnings.warn(f"scat_amd.streams: {res['shared']} share a hardware queue after re-picking: the collectives (or the "
+                      "weight gradients) will serialise behind the other stream's kernels (~4 ms of a 23 ms step on "
+                      "MI355X, profiles/r03_dp_queues.txt)", RuntimeWarning)
+    if plan is not None:
+        plan["verified"] = res
+    return res
+
+
+def plan_report(device):
+    """what verify_collective_plan() found on this rank (None: no process group was planned)"""
+    plan = _PLAN.get(_dev(device).index)
+    return None if plan is None else plan["verified"]
 
 
 def alias(device, role, to):

@@ -13,6 +13,8 @@ import os
 
 import torch
 
+from . import _switches as _sw
+
 from . import ops
 from .dp import GradBuckets
 
@@ -48,7 +50,7 @@ def pose_length_term(pl_term):
     return ops.pose_length_term(pl_term)
 
 
-EARLY_ADAM = os.environ.get("SCAT_EARLY_ADAM", "1") != "0"
+EARLY_ADAM = _sw.ab("SCAT_EARLY_ADAM", True)
 
 
 def _aux_stream(device):

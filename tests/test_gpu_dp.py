@@ -270,3 +270,38 @@ def test_rccl_single_rank_collectives():
     got = q.get(timeout=500)
     p.join(60)
     assert isinstance(got[1], str) and got[1].startswith("OK"), got
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_through_the_launcher():
+    """``bench.py --gpus 2`` exactly as the driver launches it for N > 1 (python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 2 --master-addr 127.0.0.1 ...), both ranks on the one GPU of this box with gloo carrying the
+    collectives (RCCL refuses two ranks on one device): the launcher env is read, the process group comes up before any GPU
+    call, every rank takes its own shard, the barriers / MAX-reduce of the wall time / gathered per-rank evidence run,
+    rank 0 prints ONE JSON line for the whole job.  (this branch of bench.py had never executed.)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCAT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 192 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - 192 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-2 * d["value"]
+    import math
+    assert math.isfinite(d["config"]["final_loss"])
+    dp = d["config"]["data_parallel"]
+    assert dp["world"] == 2 and dp["backend"] == "gloo" and dp["collectives_per_step"] == 7
+    assert sorted(x["rank"] for x in dp["per_rank"]) == [0, 1]
+    assert sum(dp["bucket_bytes"].values()) >= 4 * 29_401_307
+    assert d["roofline"] is not None and d["roofline"]["frac"] > 0

@@ -488,6 +488,42 @@ def test_batchnorm(ops, B, C, H):
     assert rel_err(ops.bn_apply(xg, sc_e, sh_e), ye) < 1e-5
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("C,H", [(256, 56), (512, 28)])
+def test_batchnorm_backward_batch96(ops, C, H):
+    """The BatchNorm-backward grids of a batch-96 step (VERDICT r03 "Next" item 2): bn_bwd and bn_bwd_pre on
+    (96, 256, 56, 56) and (96, 512, 28, 28) — bn_bwd_reduce_g_kernel's largest launch is reached by no smaller test —
+    against fp64 torch autograd of relu(batch_norm(x) + res): dx (materialised, and as formed from bn_bwd_pre's three
+    per-channel constants), dgamma, dbeta, the masked residual gradient."""
+    B = 96
+    gen = torch.Generator().manual_seed(900 + C)
+    x = torch.randn((B, C, H, H), generator=gen) * 1.7 + 0.4
+    res = torch.randn((B, C, H, H), generator=gen)
+    dy = torch.randn((B, C, H, H), generator=gen)
+    gamma = torch.from_numpy(synth.uniform(18, "g", (C,), 0.5, 1.5))
+    beta = torch.from_numpy(synth.uniform(19, "b", (C,), -0.3, 0.3))
+    xd, gd, bd = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y = F.relu(F.batch_norm(xd, None, None, gd, bd, True, 0.1, 1e-5) + res.double())
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(y, (xd, gd, bd), dy.double())
+    dres_ref = (dy.double() * (y > 0)).float()
+    del y
+    xg, gg, bg = g(x), g(gamma), g(beta)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, invstd, scale, shift = ops.bn_train_stats(xg, gg, bg, rm, rv)
+    yg, mask = ops.bn_apply(xg, scale, shift, g(res), True, want_mask=True)
+    dres = torch.empty_like(xg)
+    dxg, dgg, dbg = ops.bn_bwd(g(dy), xg, None, True, scale, shift, mean, invstd, gg, dres=dres, y_mask=mask)
+    assert rel_err(dxg, dx_ref) < 2e-5 and rel_err(dgg, dg_ref) < 2e-5 and rel_err(dbg, db_ref) < 2e-5
+    assert rel_err(dres, dres_ref) < 1e-6
+    del dxg, dres
+    gbuf = g(dy)
+    coef3, dg2, db2 = ops.bn_bwd_pre(gbuf, xg, True, scale, shift, mean, invstd, gg, y_mask=mask)
+    assert rel_err(gbuf, dres_ref) < 1e-6
+    assert rel_err(dg2, dg_ref) < 2e-5 and rel_err(db2, db_ref) < 2e-5
+    gbuf.mul_(coef3[0].view(1, -1, 1, 1)).addcmul_(xg, coef3[1].view(1, -1, 1, 1)).add_(coef3[2].view(1, -1, 1, 1))
+    assert rel_err(gbuf, dx_ref) < 2e-5
+
+
 @pytest.mark.parametrize("B,cin,cout,k,s,p,H,W", [(3, 64, 256, 1, 1, 0, 28, 28), (2, 128, 64, 1, 1, 0, 13, 9),
                                                    (3, 64, 64, 3, 1, 1, 20, 24), (2, 32, 32, 3, 1, 1, 11, 9),
                                                    (2, 128, 128, 3, 2, 1, 28, 28), (2, 3, 64, 7, 2, 3, 64, 96),
@@ -1316,3 +1352,51 @@ def test_batchnorm_backward_through_maxpool_survives_garbage_taps(ops):
     dx, dg, db = ops.bn_bwd_maxpool(dy, idx, x, True, one, zero, zero, one, one)
     torch.cuda.synchronize()
     assert torch.isfinite(dx).all() and torch.isfinite(dg).all()
+
+
+# ---------------------------------------------------------------- activations as pre-split bf16 planes (csrc/planes.hip)
+
+def test_planes_are_the_exact_fp32_values(ops):
+    """scat_planes_from_f32: hi + mid + lo reproduces every fp32 value exactly (3 x 8 significand bits), with and
+    without the fused BatchNorm + ReLU, on planes whose pixel count is / is not a multiple of 4."""
+    for n, (B, C, H) in enumerate([(3, 32, 14), (2, 64, 7), (2, 8, 5), (1, 96, 28)]):
+        x = g(t(700 + n, "x", (B, C, H, H)) * 3.0)
+        assert torch.equal(ops.planes_from(x).to_f32(), x)
+        sc, sh = g(t(710 + n, "sc", (C,))), g(t(720 + n, "sh", (C,)))
+        ref = torch.relu(torch.addcmul(sh.view(1, -1, 1, 1), x, sc.view(1, -1, 1, 1)))     # one fma per element
+        got = ops.planes_from(x, sc, sh, True).to_f32()
+        assert rel_err(got.cpu(), torch.relu(x.cpu().double() * sc.cpu().double().view(1, -1, 1, 1)
+                                             + sh.cpu().double().view(1, -1, 1, 1)).float()) < 2e-7
+        assert float((got < 0).sum()) == 0
+        ref2 = ops.planes_from(x, sc, sh, False).to_f32()
+        assert rel_err(ref2.cpu(), (x.cpu().double() * sc.cpu().double().view(1, -1, 1, 1)
+                                    + sh.cpu().double().view(1, -1, 1, 1)).float()) < 2e-7
+
+
+@pytest.mark.parametrize("cin,cout,H,B", [(64, 256, 56, 2), (256, 64, 56, 2), (128, 512, 28, 3), (512, 128, 28, 3),
+                                          (256, 1024, 14, 5), (1024, 256, 14, 5), (512, 2048, 7, 7), (2048, 512, 7, 7),
+                                          (32, 64, 9, 3), (96, 224, 5, 2)])
+def test_conv1x1_planes_bit_identical(ops, cin, cout, H, B):
+    """scat_conv1x1_planes (activations as planes, LDS-DMA staging) against scat_conv1x1_s1 (in-kernel split): the MFMA
+    stream is the same, so forward, data gradient, accumulate and the epilogue's BatchNorm sums must agree BIT FOR BIT;
+    ragged tiles (pixel count not a multiple of 128, rows not a multiple of 32) included.  Both LDS ring depths."""
+    assert ops.get_math_mode() == 1
+    x = g(t(730, "x", (B, cin, H, H)))
+    w = g(t(731, "w", (cout, cin, 1, 1), std=(2.0 / cin) ** 0.5))
+    dy = g(t(732, "dy", (B, cout, H, H)))
+    sc, sh = g(t(733, "sc", (cin,)).abs() + 0.5), g(t(734, "sh", (cin,)))
+    base = g(t(735, "base", (B, cin, H, H)))
+    ref_f = ops.conv2d_fwd(x, w, 1, 0)
+    ref_tf = ops.conv2d_fwd(x, w, 1, 0, sc, sh, True)
+    ref_d = ops.conv2d_dgrad_w(dy, w, tuple(x.shape), 1, 0)
+    ref_da = ops.conv2d_dgrad_w(dy, w, tuple(x.shape), 1, 0, out=base.clone(), accumulate=True)
+    xp, xtp, dyp = ops.planes_from(x), ops.planes_from(x, sc, sh, True), ops.planes_from(dy)
+    for nb in (0, 2, 3):
+        assert torch.equal(ops.conv1x1_planes(xp, w, lds_stages=nb), ref_f)
+        assert torch.equal(ops.conv1x1_planes(xtp, w, lds_stages=nb), ref_tf)
+        assert torch.equal(ops.conv1x1_planes(dyp, w, transposed=True, lds_stages=nb), ref_d)
+        assert torch.equal(ops.conv1x1_planes(dyp, w, transposed=True, out=base.clone(), accumulate=True,
+                                              lds_stages=nb), ref_da)
+    # against the torch op itself
+    want = F.conv2d(x.cpu().double(), w.cpu().double()).float()
+    assert rel_err(ops.conv1x1_planes(xp, w).cpu(), want) < 2e-5

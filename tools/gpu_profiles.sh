@@ -1,5 +1,7 @@
 #!/bin/bash
 # Round-3 evidence: everything that ends up under profiles/r03_* (run on the GPU box, outputs in gpurun_out/)
+set -u
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the copy of the repository there)}"
 cd "$GRAFT_REPO_ROOT"
 O=$GRAFT_REPO_ROOT/gpurun_out
 R=${1:-r03}
@@ -25,7 +27,7 @@ prof() {
   rm -rf $O/prof_$name
 }
 prof default A=1
-prof serialized SCAT_SIDE_WGRAD=0 SCAT_OVERLAP_TOKENS=0 SCAT_EARLY_ADAM=0
+prof serialized SCAT_DIAG=1 SCAT_SIDE_WGRAD=0 SCAT_OVERLAP_TOKENS=0 SCAT_EARLY_ADAM=0
 echo "[profiles] traffic"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$c

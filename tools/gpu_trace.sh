@@ -1,5 +1,7 @@
 #!/bin/bash
 # kernel trace of the bench step -> kernel summary, idle-gap summary and the timeline around the gaps
+set -u
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the copy of the repository there)}"
 cd "$GRAFT_REPO_ROOT"
 O=$GRAFT_REPO_ROOT/gpurun_out
 N=${1:-r03}

@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage: tools/pmc_run.sh OUTDIR "COUNTERS" -- python3 tools/conv_bench.py ...   (on the GPU box; one --pmc pass)
+set -u
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the copy of the repository there)}"
 set -e
 out=$1; shift; ctr=$1; shift; shift
 cd /tmp && export TMPDIR=/tmp
