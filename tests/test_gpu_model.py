@@ -602,19 +602,33 @@ def test_layer4_standalone_on_7x7_maps():
     held(xb.grad, {"2." + k: p.grad for k, p in blk.named_parameters()}, b32, b64, "layer4.2")
 
 
-@pytest.mark.timeout(1500)
+@pytest.mark.timeout(1700)
 @pytest.mark.parametrize("key,cin,H,stride", [("layer1.0", 64, 56, 1), ("layer2.0", 256, 56, 2), ("layer3.1", 1024, 14, 1),
                                               ("layer4.2", 2048, 7, 1)])
 def test_bottleneck_batch96_against_fp64(key, cin, H, stride):
-    """The COMPOSED fused block at the benchmarked size (VERDICT r03 "Next" item 2; models/resnet.py:78-98): one
-    stand-alone Bottleneck at batch 96, train mode — BatchNorm sums in the convolution epilogues and their finish, bn1 /
-    bn2 folded into the next operand load, bn3 (+ the shortcut's BatchNorm) + residual + ReLU with the 1-bit sign mask,
-    and in the backward bn_bwd_pre / the folded-BatchNorm gradient kernels (56x56 / 28x28 planes), the one-pass
-    BatchNorm backward (14x14, 7x7), the packed stride-2 shortcut, accumulate-on-residual — against the oracle's
-    Bottleneck evaluated in fp64 on the same tensors.  A single block is well conditioned: forward 2e-5, every gradient
-    (dx, dW, dgamma, dbeta) 2e-4, running statistics 1e-5.  The blocks: layer1.0 (56x56, shortcut convolution, folded
-    bn3 backward), layer2.0 (stride 2, packed shortcut), layer3.1 (14x14, one-pass BatchNorm backward), layer4.2 (7x7,
-    no sign mask: the output is kept)."""
+    """The COMPOSED fused block at the benchmarked size (VERDICT r03 "Next" item 2; models/resnet.py:78-98): the block
+    executor of the fused backbone (resnet._block_forward / _block_backward, what Bottleneck.forward runs) on one
+    Bottleneck at batch 96, train mode — BatchNorm sums in the convolution epilogues and their finish, bn1 / bn2 folded
+    into the next operand load, bn3 (+ the shortcut's BatchNorm) + residual + ReLU with the 1-bit sign mask, and in the
+    backward bn_bwd_pre / the folded-BatchNorm gradient kernels (56x56 / 28x28 planes), the one-pass BatchNorm backward
+    (14x14, 7x7), the packed stride-2 shortcut, accumulate-on-residual — against the oracle's Bottleneck in fp64 on the
+    same tensors.  Blocks: layer1.0 (56x56, shortcut convolution, folded bn3 backward), layer2.0 (stride 2, packed
+    shortcut), layer3.1 (14x14, one-pass BatchNorm backward), layer4.2 (7x7, no sign mask: the output is kept).
+
+    How the gradient gate is made TIGHT.  At this size a block has 10-40 million ReLU inputs, a few dozen of them within
+    one fp32 rounding of zero: any fp32 evaluation flips those against fp64 and every flip is an O(1) change of the
+    gradient at that element — measured, the oracle itself in fp32 on the CPU is 4e-2 (max) / 1e-3 (L2) from fp64 on
+    layer1.0's dx (gpurun_out/b96_block_parity.json).  That is the network's conditioning, not the kernels'.  So:
+      1. forward against plain fp64: 2e-5; running statistics 1e-5;
+      2. the three ReLU sign patterns of the HIP run (bn1 / bn2: sign of fma(c, scale, shift) exactly as the kernels
+         form it; block output: its sign) may disagree with fp64's only where fp64's pre-activation is itself within
+         2e-5 of zero (relative to its largest value), and in fewer than 2e-5 of the elements;
+      3. every gradient (dx, dW, dgamma, dbeta) against the fp64 evaluation of the same block WITH THOSE sign patterns
+         (relu(z) -> z * mask): no flips left, and the gate is 2e-4 norm-wise maximum — what a wrong reduction grid, a
+         missing 1/N or a misplaced mask would exceed by orders of magnitude."""
+    import json
+    import os
+    import torch.nn.functional as F
     from scat_amd.models import resnet as R
 
     B = 96
@@ -627,27 +641,82 @@ def test_bottleneck_batch96_against_fp64(key, cin, H, stride):
     Ho = H // stride
     cot = T(synth.normal_like(53, "cot" + key, (B, blk.conv3.weight.shape[0], Ho, Ho)))
 
-    sd = {k[len(key) + 1:]: (v.detach().clone().double() if v.is_floating_point() else v.clone())
-          for k, v in full.items() if k.startswith(key + ".")}
-    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
-    xr = x.double().requires_grad_(True)
-    yr = O.bottleneck({("b." + k): v for k, v in sd.items()}, "b", xr, stride, True)
-    (yr * cot.double()).sum().backward()
+    # ---- HIP: the block executor itself (so that the tape's raw convolution outputs are at hand for the sign patterns)
+    R._NBT.clear()
+    rec = R._block_forward(blk, x.cuda(), True, None)
+    torch._foreach_add_(R._NBT, 1)
+    R._NBT.clear()
+    _, _, c1, s1, c2, s2, c3, s3, cd, sd, out, omask = rec
+    m1 = (c1.double() * s1.scale.double().view(1, -1, 1, 1) + s1.shift.double().view(1, -1, 1, 1) > 0).cpu()
+    m2 = (c2.double() * s2.scale.double().view(1, -1, 1, 1) + s2.shift.double().view(1, -1, 1, 1) > 0).cpu()
+    m3 = (out > 0).cpu()
+    bc = R._Bwd(None, out.device, None)
+    dx = R._block_backward(bc, rec, cot.cuda().clone())
+    bc.join()
+    torch.cuda.synchronize()
+    got = {"dx": dx}
+    got.update({k: bc.grads[p] for k, p in blk.named_parameters()})
 
-    xg = x.cuda().requires_grad_(True)
-    y = blk(xg)
-    assert rel_err(y, yr.detach()) < 2e-5, rel_err(y, yr.detach())
-    (y * cot.cuda()).sum().backward()
-    errs = {"dx": rel_err(xg.grad, xr.grad)}
-    for k, p in blk.named_parameters():
-        errs[k] = rel_err(p.grad, leaves[k].grad)
-    worst = max(errs, key=errs.get)
-    assert errs[worst] < 2e-4, (key, worst, errs[worst], errs)
+    # ---- fp64: plain (forward, statistics, its own sign patterns) ...
+    def state():
+        return {("b." + k[len(key) + 1:]): (v.detach().clone().double() if v.is_floating_point() else v.clone())
+                for k, v in full.items() if k.startswith(key + ".")}
+
+    sd64 = state()
+    with torch.no_grad():
+        z = {}
+
+        def bn(k, t):
+            return O.batch_norm(sd64, "b." + k, t, True)
+
+        xd = x.double()
+        z1 = bn("bn1", F.conv2d(xd, sd64["b.conv1.weight"]))
+        z2 = bn("bn2", F.conv2d(F.relu(z1), sd64["b.conv2.weight"], stride=stride, padding=1))
+        z3 = bn("bn3", F.conv2d(F.relu(z2), sd64["b.conv3.weight"]))
+        res = xd
+        if "b.downsample.0.weight" in sd64:
+            res = bn("downsample.1", F.conv2d(xd, sd64["b.downsample.0.weight"], stride=stride))
+        z3 = z3 + res
+        y64 = F.relu(z3)
+    assert rel_err(out, y64) < 2e-5, rel_err(out, y64)
+    flips = {}
+    for name, zz, m in (("bn1", z1, m1), ("bn2", z2, m2), ("out", z3, m3)):
+        bad = (zz > 0) != m
+        nbad = int(bad.sum())
+        worst = float(zz[bad].abs().max() / zz.abs().max()) if nbad else 0.0
+        flips[name] = {"disagreeing": nbad, "of": zz.numel(), "largest_fp64_preactivation_rel": worst}
+        assert nbad <= 2e-5 * zz.numel() and worst < 2e-5, (key, name, flips[name])
+    del z1, z2, z3, y64
+
+    # ---- ... and with the HIP run's sign patterns in place of its own: the gradient reference
+    sdm = state()
+    leaves = {k[2:]: v.requires_grad_(True) for k, v in sdm.items() if v.is_floating_point() and "running" not in k}
+    xr = x.double().requires_grad_(True)
+    a1 = O.batch_norm(sdm, "b.bn1", F.conv2d(xr, sdm["b.conv1.weight"]), True) * m1
+    a2 = O.batch_norm(sdm, "b.bn2", F.conv2d(a1, sdm["b.conv2.weight"], stride=stride, padding=1), True) * m2
+    o3 = O.batch_norm(sdm, "b.bn3", F.conv2d(a2, sdm["b.conv3.weight"]), True)
+    res = xr
+    if "b.downsample.0.weight" in sdm:
+        res = O.batch_norm(sdm, "b.downsample.1", F.conv2d(xr, sdm["b.downsample.0.weight"], stride=stride), True)
+    ((o3 + res) * m3 * cot.double()).sum().backward()
+    ref = {"dx": xr.grad}
+    ref.update({k: v.grad for k, v in leaves.items()})
+
+    rows = {k: rel_err(got[k], ref[k]) for k in ref}
+    outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(outdir, exist_ok=True)
+    path = os.path.join(outdir, "b96_block_parity.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc[key] = {"forward_max": rel_err(out, F.relu(o3 + res).detach()), "sign_patterns": flips,
+                "gradients_max_vs_fp64_with_the_same_signs": rows}
+    json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
+    worst = max(rows, key=rows.get)
+    assert rows[worst] < 2e-4, (key, worst, rows)
     for k, v in blk.named_buffers():
         if "running" in k:
-            assert rel_err(v, sd[k]) < 1e-5, (key, k)
+            assert rel_err(v, sd64["b." + k]) < 1e-5, (key, k)
         elif "num_batches_tracked" in k:
-            assert int(v) == int(sd[k]) == 1
+            assert int(v) == int(sd64["b." + k]) == 1
 
 
 def test_config0_as_stated():

@@ -716,7 +716,8 @@ def test_layernorm(ops, rows, dim):
     assert rel_err(dxg, dx) < 1e-5 and rel_err(dgg, dg) < 1e-5 and rel_err(dbg, db) < 1e-5
 
 
-@pytest.mark.parametrize("B,n,heads", [(4, 21, 8), (2, 128, 8), (3, 65, 2), (2, 21, 16)])
+@pytest.mark.parametrize("B,n,heads", [(4, 21, 8), (2, 128, 8), (3, 65, 2), (2, 21, 16), (3, 64, 3), (2, 96, 5),
+                                       (96, 128, 8)])
 def test_attention_core(ops, B, n, heads):
     d = 64
     qkv = t(35, "qkv", (B, n, 3 * heads * d)).requires_grad_(True)

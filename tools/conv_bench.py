@@ -20,7 +20,8 @@ SHAPES = [  # Cin, Cout, k, s, p, H
     (256, 1024, 1, 1, 0, 14), (512, 1024, 1, 2, 0, 28), (1024, 256, 1, 1, 0, 14), (256, 256, 3, 1, 1, 14),
     (1024, 512, 1, 1, 0, 14), (512, 512, 3, 2, 1, 14), (512, 2048, 1, 1, 0, 7), (1024, 2048, 1, 2, 0, 14),
     (2048, 512, 1, 1, 0, 7), (512, 512, 3, 1, 1, 7),
-    # 23-25: the stride-2 shortcut convolutions seen as stride-1 on a pre-subsampled input
+    # 23-25: the stride-2 shortcut convolutions as the step runs their forward and weight gradient: stride-1 on the input
+    # packed by scat_subsample2 (rows 8, 14, 20 are the same layers called unpacked: only their data gradient is on the step)
     (256, 512, 1, 1, 0, 28), (512, 1024, 1, 1, 0, 14), (1024, 2048, 1, 1, 0, 7),
     # 26-29: HRNet-W32's branch convolutions (models/hrnet.py:38-63)
     (32, 32, 3, 1, 1, 56), (64, 64, 3, 1, 1, 28), (128, 128, 3, 1, 1, 14), (256, 256, 3, 1, 1, 7),
@@ -63,6 +64,9 @@ def main():
         byts = 4.0 * (x.numel() + y.numel() + w.numel())
         name = f"{cin}->{cout} k{k} s{s} {H}x{H}"
         for kind in kinds:
+            # what a ResNet-50 step launches: the 1x1 / stride-2 shortcuts run forward and weight gradient packed (rows
+            # 23-25) and only the data gradient in this geometry; the packed rows have no data gradient of their own
+            on_step = not ((k == 1 and s == 2 and kind != "dgrad") or (i in (23, 24, 25) and kind == "dgrad"))
             if kind == "fwd":
                 fn = lambda: ops.conv2d_fwd(x, w, s, p, out=y)
             elif kind == "dgrad":
@@ -76,12 +80,13 @@ def main():
             us = timeit(fn, a.reps)
             label = L.scat_last_kernel().decode()
             print(f"{name:34s} {kind:6s} {label:42s} {us:8.1f} {flops / us / 1e6:7.1f} {flops / 157.3e6:8.1f} "
-                  f"{byts / 6.3e6:7.1f}", flush=True)
-            tot[kind][0] += us
-            tot[kind][1] += flops
+                  f"{byts / 6.3e6:7.1f}{'' if on_step else '   (not on the step)'}", flush=True)
+            if on_step:
+                tot[kind][0] += us
+                tot[kind][1] += flops
     for kind, (us, fl) in tot.items():
         if us:
-            print(f"TOTAL {kind}: {us / 1e3:.2f} ms, {fl / us / 1e6:.1f} TF")
+            print(f"TOTAL {kind} (rows on the step, one call each): {us / 1e3:.2f} ms, {fl / us / 1e6:.1f} TF")
 
 
 if __name__ == "__main__":

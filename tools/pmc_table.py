@@ -24,7 +24,7 @@ for d in sys.argv[1:]:
     print("==", d)
     for (did, name), c in disp.items():
         if not any(k in name for k in ("gemm_kernel", "halo", "split_kernel", "conv1x1_kernel", "pc_kernel", "pw_kernel",
-                                       "vit_")) or "wt3x3" in name:
+                                       "vit_", "planes_kernel", "attn_mfma")) or "wt3x3" in name:
             continue
         short = re.sub(r"scat::|Loader|void ", "", name)[:70]
         seen[short] += 1
