@@ -157,6 +157,19 @@ int scat_conv2d_wt(const float* w, float* wt, int Cout, int Cin, int KH, int KW,
 /* dw[Cout,Cin,KH,KW] = sum over pixels dy * relu(x*scale+shift).  Deterministic two-stage
  * split-K (no float atomics).  ws: scat_conv2d_wgrad_ws() bytes. */
 int64_t scat_conv2d_wgrad_ws(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad);
+/* ---- deferred split-K reduces ----
+ * Every weight-gradient entry point ends with the fixed-order sum of its split-K slabs: 54 launches of 6-12 us in a
+ * ResNet-50 backward.  After scat_splitk_defer(1) (per host thread) those sums are recorded instead of launched — the
+ * caller then owes every recorded contraction a workspace of its own until scat_splitk_reduce_flush(stream) performs
+ * them all with one grouped launch (per 48 jobs) on that stream, which must be ordered after the contractions.
+ * scat_splitk_reduce_pending() = recorded and not yet flushed; scat_splitk_reduce_discard() forgets them (start of a
+ * new backward after an aborted one).  Deterministic: a job's result depends on its split count only.  No reference
+ * counterpart (autograd of nn.Conv2d, models/resnet.py:65-72). */
+int scat_splitk_defer(int on);
+int scat_splitk_reduce_pending(void);
+int scat_splitk_reduce_discard(void);
+int scat_splitk_reduce_flush(void* stream);
+
 int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout, int KH,
                       int KW, int stride, int pad, const float* in_scale, const float* in_shift, int in_relu,
                       void* ws, int64_t ws_bytes, void* stream);

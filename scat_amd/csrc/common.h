@@ -87,6 +87,10 @@ static inline long long diag_env_int(const char* name, long long dflt) {
 #endif
 }
 
+// Cache policy of a kernel's bulk output stores, by the size of the tensor written (misc.hip): 0 = default, 2 = nt
+// (non-temporal: the lines are not kept in the caches), 16 = sc1.  See DESIGN.md 1d.
+int store_policy(int64_t out_bytes);
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 static inline bool fits_i32(int64_t n) { return n >= 0 && n < (1ll << 31); }

@@ -1235,6 +1235,7 @@ static void launch_pw_split(const PwDesc& d, const OutDesc& dc_in, hipStream_t s
         dc.sg = nt * (4 / WM);
         dc.stats = epi_stats_take(d.M, dc.sg, &dc.stats_shift);
     }
+    if (!dc.accumulate) dc.st_aux = store_policy(dc.n * 4);
     if constexpr (!STEM && BN == 128) {
         // persistent stream-K grid when the caller armed a scratch buffer and the launch has enough tiles to share out
         SkDesc sk{};

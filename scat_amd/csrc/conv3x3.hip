@@ -440,6 +440,7 @@ static void launch_split(const HaloDesc& d, const OutDesc& dc_in, hipStream_t st
         dc.sg = nt * (4 / WM);
         dc.stats = epi_stats_take(d.M, dc.sg, &dc.stats_shift);
     }
+    if (!dc.accumulate) dc.st_aux = store_policy(dc.n * 4);
     auto kern = conv3x3_split_kernel<WM, HB_N, TF>;
     hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(NT), lds_bytes, st, d, dc);
 }

@@ -1,5 +1,7 @@
 // Convolution weight-gradient: dW[Cout][Cin*KH*KW] = dY[Cout][pixels] * im2col(X)[pixels][Cin*KH*KW],
 // contraction over B*OH*OW pixels, deterministic two-stage split-K (slabs + fixed-order sum).
+#include <vector>
+
 #include "conv_common.h"
 
 namespace scat {
@@ -71,8 +73,88 @@ __global__ __launch_bounds__(64 * WAVES) void splitk_reduce4_kernel(const float4
     out[e] = s;
 }
 
+// ---- deferred reduces: ONE grouped launch for the fixed-order sums of many weight gradients
+// A ResNet-50 backward issues 54 of the launches above, 6-12 us each, every one behind its contraction on the weight-
+// gradient stream.  With scat_splitk_defer(1) in force (per host thread) a reduce is not launched but recorded; the caller
+// keeps every recorded slab intact (its own workspace per contraction) until scat_splitk_reduce_flush() sums them all
+// with one launch: a workgroup finds its job in a table passed in the kernel arguments (<= 48 jobs per launch) and runs
+// the four-wavefront body above — the result depends on (splits, 4) only, bit-reproducible like the single launches.
+struct ReduceJob {
+    const float4* slab;
+    float4* out;
+    int64_t n4;
+    int splits, accumulate, blk0, pad;
+};
+constexpr int RG_MAX = 48;
+struct ReduceTable {
+    ReduceJob j[RG_MAX];
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceTable t) {
+    __shared__ float4 part[4][64];
+    int lo = 0, hi = t.njobs - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.j[mid].blk0 <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const float4* __restrict__ slab = t.j[lo].slab;
+    float4* __restrict__ out = t.j[lo].out;
+    const int64_t n4 = t.j[lo].n4;
+    const int splits = t.j[lo].splits, accumulate = t.j[lo].accumulate;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t e = (int64_t)(b - t.j[lo].blk0) * 64 + lane;
+    const bool live = e < n4;
+    const int per = (splits + 3) / 4;
+    const int z0 = wave * per, z1 = min(z0 + per, splits);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = slab[(int64_t)(z + q) * n4 + e];
+            s.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+            s.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+            s.z += ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
+            s.w += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
+        }
+        for (; z < z1; ++z) {
+            const float4 v = slab[(int64_t)z * n4 + e];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave != 0 || !live) return;
+    s = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const float4 v = part[w][lane];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (accumulate) {
+        const float4 o = out[e];
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    out[e] = s;
+}
+
+struct ReduceDefer {
+    bool on = false;
+    std::vector<ReduceJob> jobs;
+};
+static thread_local ReduceDefer g_rdefer;
+
 void launch_splitk_reduce(const float* slab, float* out, int64_t n, int splits, int accumulate, hipStream_t st) {
     static const int vec = diag_env_int("SCAT_REDUCE_VEC", 1);
+    if (g_rdefer.on && n % 4 == 0 && (((uintptr_t)slab | (uintptr_t)out) & 15) == 0 && n / 4 < (1ll << 30)) {
+        g_rdefer.jobs.push_back(ReduceJob{(const float4*)slab, (float4*)out, n / 4, splits, accumulate, 0, 0});
+        append_kernel_label("_rdefer");
+        return;
+    }
     if (vec && n % 4 == 0 && (((uintptr_t)slab | (uintptr_t)out) & 15) == 0) {
         const int64_t n4 = n / 4;
         const dim3 grid((unsigned)((n4 + 63) / 64));
@@ -315,5 +397,35 @@ extern "C" int scat_conv2d_wgrad(const float* dy, const float* x, float* dw, int
         launch_splitk_reduce((const float*)ws, dw, n, p.splits, 0, st);
         SCAT_LAUNCH_CHECK("scat_conv2d_wgrad(reduce)");
     }
+    return SCAT_OK;
+}
+
+
+/* Deferred split-K reduces (include/scat_hip.h). */
+extern "C" int scat_splitk_defer(int on) {
+    scat::g_rdefer.on = on != 0;
+    return SCAT_OK;
+}
+extern "C" int scat_splitk_reduce_pending(void) { return (int)scat::g_rdefer.jobs.size(); }
+extern "C" int scat_splitk_reduce_discard(void) {
+    scat::g_rdefer.jobs.clear();
+    return SCAT_OK;
+}
+extern "C" int scat_splitk_reduce_flush(void* stream) {
+    auto& jobs = scat::g_rdefer.jobs;
+    hipStream_t st = (hipStream_t)stream;
+    for (size_t i = 0; i < jobs.size(); i += scat::RG_MAX) {
+        scat::ReduceTable t{};
+        int blk = 0;
+        t.njobs = (int)(jobs.size() - i < (size_t)scat::RG_MAX ? jobs.size() - i : (size_t)scat::RG_MAX);
+        for (int k = 0; k < t.njobs; ++k) {
+            t.j[k] = jobs[i + k];
+            t.j[k].blk0 = blk;
+            blk += (int)((t.j[k].n4 + 63) / 64);
+        }
+        hipLaunchKernelGGL(scat::splitk_reduce_group_kernel, dim3(blk), dim3(256), 0, st, t);
+    }
+    jobs.clear();
+    SCAT_LAUNCH_CHECK("scat_splitk_reduce_flush");
     return SCAT_OK;
 }

@@ -73,6 +73,7 @@ struct OutDesc {
     float* stats;         // optional: per-row (sum, sum of squares) of every wavefront's live columns of the tile,
     int sg;               //   stats[(row * sg + group) * 2 + {0, 1}], group = tile column * WN + wn  (BatchNorm statistics
                           //   of a convolution's output without reading it back: scat_epilogue_stats_arm)
+    int st_aux;                 // cache policy of the epilogue's stores (store_tile): 0 default, 16 sc1, 2 nt
     const float* stats_shift;   // optional per-row reference c[row]: the sums are of (x - c) and (x - c)^2 — fp32 partials of
                                 // x^2 cancel catastrophically in E[x^2] - mean^2 when |mean| >> sigma (scat_epilogue_stats_arm_shift)
 };
@@ -458,11 +459,27 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[MI][NI], const OutDesc&
 #pragma unroll
                         for (int b = 0; b < NI; ++b) val[rr][b] += old[rr][b];
                 }
+                // cache policy of the output stores (OutDesc::st_aux): 0 = default (the line stays in the XCD's L2),
+                // 16 = sc1 (written through, the line is dropped from L2), 2 = nt
+                if (dc.st_aux == 16) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
+                    for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                    for (int b = 0; b < NI; ++b)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[rr][b]), rc, voff[rr][b], 0, 0);
+                        for (int b = 0; b < NI; ++b)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[rr][b]), rc, voff[rr][b], 0, 16);
+                } else if (dc.st_aux == 2) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[rr][b]), rc, voff[rr][b], 0, 2);
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[rr][b]), rc, voff[rr][b], 0, 0);
+                }
             }
         }
     };

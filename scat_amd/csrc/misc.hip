@@ -53,6 +53,18 @@ int math_mode() {
     return g_math_mode;
 }
 
+// Bulk output stores of tensors of 200 MiB and more (at batch 96: the 256-channel 56 x 56 maps and the stem's output,
+// 294 MiB each) are non-temporal: such a tensor cannot stay in the 256 MiB Infinity Cache anyway, and written with the
+// default policy it evicts what the next kernels would have found there.  Measured (profiles/r04_store_policy.txt,
+// r04_ab_store_nt.txt): 64->256 @56x56 forward 108 -> 79 us alone; train step 23.89 -> 23.71 ms with the threshold at
+// 100 or 200 MiB, no gain with nt everywhere (smaller outputs ARE re-read from the cache), sc1 0.6 % slower.
+// (SCAT_STORE_AUX / SCAT_STORE_NT_MIN_MB: tools build only.)
+int store_policy(int64_t out_bytes) {
+    static const int aux = (int)diag_env_int("SCAT_STORE_AUX", 2);
+    static const int64_t min_b = diag_env_int("SCAT_STORE_NT_MIN_MB", 200) << 20;
+    return out_bytes >= min_b ? aux : 0;
+}
+
 int tuning() {
     static int v = diag_env_int("SCAT_TUNE", 0);
     return v;

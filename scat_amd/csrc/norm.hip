@@ -294,6 +294,13 @@ __global__ void bn_eval_fold_kernel(const float* gamma, const float* beta, const
 
 // ---------------------------------------------------------------- BN apply
 
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+// a 16-byte store with the cache policy of store_policy(): nt for bulk outputs that nothing re-reads soon
+__device__ __forceinline__ void st4(float4* p, const float4 v, const int nt) {
+    if (nt) __builtin_nontemporal_store(v4f_t{v.x, v.y, v.z, v.w}, (v4f_t*)p);
+    else *p = v;
+}
+
 // flat element-wise pass; channel of element e = (e / HW) % C by mul-shift division
 template <int V>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ rscale,
                                                        const float* __restrict__ rshift, int relu,
                                                        float* __restrict__ y, uint8_t* __restrict__ mask,
-                                                       int64_t nvec, FastDiv dHWv, FastDiv dC) {
+                                                       int64_t nvec, FastDiv dHWv, FastDiv dC, int nt) {
     for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < nvec; e += gridDim.x * 256ll) {
         const uint32_t row = dHWv.div((uint32_t)e);
         const int c = (int)(row - dC.div(row) * dC.d);
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            ((float4*)y)[e] = v;
+            st4((float4*)y + e, v, nt);
             // sign bits of the output, one byte per float4: what the backward needs of y (32x fewer bytes)
             if (mask) mask[e] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
         } else {
@@ -762,7 +769,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ coef, float* dx,
                                                            float* dres, int dres_acc, int64_t nvec, FastDiv dHWv,
-                                                           FastDiv dC) {
+                                                           FastDiv dC, int nt) {
     const bool has_m = V == 4 && ymask != nullptr;
     const bool has_y = yout != nullptr || has_m;
     for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < nvec; e += gridDim.x * 256ll) {
@@ -792,7 +799,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
             rv[q] = ((dres && dres_acc) ? rv[q] : 0.f) + g;
         }
         if (V == 4) {
-            ((float4*)dx)[e] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            st4((float4*)dx + e, make_float4(ov[0], ov[1], ov[2], ov[3]), nt);
             if (dres) ((float4*)dres)[e] = make_float4(rv[0], rv[1], rv[2], rv[3]);
         } else {
             dx[e] = ov[0];
@@ -1003,11 +1010,11 @@ extern "C" int scat_bn_apply(const float* x, const float* scale, const float* sh
     if (vec) {
         const int64_t nv = total / 4;
         hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_grid(nv)), dim3(256), 0, st, x, scale, shift, residual, res_scale,
-                           res_shift, relu, y, mask_out, nv, FastDiv::make(HW / 4), FastDiv::make(C));
+                           res_shift, relu, y, mask_out, nv, FastDiv::make(HW / 4), FastDiv::make(C), store_policy(total * 4) == 2);
     } else {
         SCAT_REQUIRE(!mask_out, SCAT_E_SHAPE, "scat_bn_apply: the sign mask needs HW % 4 == 0 and 16-B aligned tensors");
         hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, x, scale, shift, residual, res_scale,
-                           res_shift, relu, y, nullptr, total, FastDiv::make(HW), FastDiv::make(C));
+                           res_shift, relu, y, nullptr, total, FastDiv::make(HW), FastDiv::make(C), 0);
     }
     SCAT_LAUNCH_CHECK("scat_bn_apply");
     return SCAT_OK;
@@ -1075,11 +1082,11 @@ extern "C" int scat_bn_bwd(const float* dy, const float* x, const float* y_out, 
         const int64_t nv = total / 4;
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(nv)), dim3(256), 0, st, dy, x, y_out, y_mask, relu,
                            scale, shift, save_mean, save_invstd, gamma, (const float*)coef, dx, dres, dres_accumulate, nv,
-                           FastDiv::make(HW / 4), FastDiv::make(C));
+                           FastDiv::make(HW / 4), FastDiv::make(C), store_policy(total * 4) == 2);
     } else {
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, dy, x, y_out, nullptr, relu,
                            scale, shift, save_mean, save_invstd, gamma, (const float*)coef, dx, dres, dres_accumulate, total,
-                           FastDiv::make(HW), FastDiv::make(C));
+                           FastDiv::make(HW), FastDiv::make(C), 0);
     }
     SCAT_LAUNCH_CHECK("scat_bn_bwd");
     return SCAT_OK;

@@ -184,6 +184,9 @@ class _Bwd:
         # — dc3 is never written or re-read (SCAT_BNB=0: materialise it, the general path)
         self.use_bnb = BNB and ops.get_math_mode() == 1
         self.pending = [None]      # a gradient contribution not yet added to dcur (see add_ext)
+        # the fixed-order sums of the weight gradients' split-K slabs are recorded by the library and performed by ONE
+        # grouped launch per join() instead of one small launch behind every contraction (ops.wgrad_defer / wgrad_flush)
+        ops.wgrad_defer_reset()
 
     def gbuf(self, p):
         return self.sink.view_for(p) if self.sink is not None else None
@@ -193,34 +196,47 @@ class _Bwd:
 
     def wgrad(self, dy, x, w, stride, pad, sc=None, sh=None, relu=False):
         out, side = self.gbuf(w), self.side
-        if side is None:
-            return ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, sc, sh, relu, out=out)
         if out is None:
             out = torch.empty_like(w)
-        side.wait_stream(self.main)
-        with torch.cuda.stream(side):
-            ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, sc, sh, relu, out=out, ws_slot="side")
-        dy.record_stream(side)
-        return out
+        ops.wgrad_defer(True)
+        try:
+            if side is None:
+                return ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, sc, sh, relu, out=out)
+            side.wait_stream(self.main)
+            with torch.cuda.stream(side):
+                ops.conv2d_wgrad(dy, x, tuple(w.shape), stride, pad, sc, sh, relu, out=out, ws_slot="side")
+            dy.record_stream(side)
+            return out
+        finally:
+            ops.wgrad_defer(False)
 
     def join(self):
+        """every weight gradient issued so far is complete on the main stream afterwards (recorded reduces included)"""
         if self.side is not None:
+            with torch.cuda.stream(self.side):
+                ops.wgrad_flush()
             self.main.wait_stream(self.side)
+        else:
+            ops.wgrad_flush()
 
     def wgrad_bnb(self, gm, z, coef, xop, w, sc=None, sh=None, relu=False):
         """conv weight gradient from a folded BatchNorm backward; returns (dw, event after the read of gm)"""
         out, side = self.gbuf(w), self.side
-        if side is None:
-            return ops.conv1x1_wgrad_bnb(gm, z, coef, xop, tuple(w.shape), sc, sh, relu, out=out), None
         if out is None:
             out = torch.empty_like(w)
-        side.wait_stream(self.main)
-        with torch.cuda.stream(side):
-            ops.conv1x1_wgrad_bnb(gm, z, coef, xop, tuple(w.shape), sc, sh, relu, out=out, ws_slot="side")
-            ev = side.record_event()
-        gm.record_stream(side)
-        coef.record_stream(side)
-        return out, ev
+        ops.wgrad_defer(True)
+        try:
+            if side is None:
+                return ops.conv1x1_wgrad_bnb(gm, z, coef, xop, tuple(w.shape), sc, sh, relu, out=out), None
+            side.wait_stream(self.main)
+            with torch.cuda.stream(side):
+                ops.conv1x1_wgrad_bnb(gm, z, coef, xop, tuple(w.shape), sc, sh, relu, out=out, ws_slot="side")
+                ev = side.record_event()       # (the contraction has read gm; its recorded reduce reads only the slabs)
+            gm.record_stream(side)
+            coef.record_stream(side)
+            return out, ev
+        finally:
+            ops.wgrad_defer(False)
 
 
 def _block_backward(bc, rec, dcur):

@@ -446,6 +446,58 @@ def conv2d_dgrad_w(dy, w, x_shape, stride, pad, out=None, accumulate=False, wp=N
     return conv2d_dgrad(dy, wt, x_shape, tuple(w.shape), stride, pad, out=out, accumulate=accumulate)
 
 
+# ---- deferred split-K reduces (include/scat_hip.h): the fixed-order sums of a stage's weight gradients as ONE launch
+WG_DEFER = _sw.ab("SCAT_WG_DEFER", False)   # measured: 22.78 vs 22.70 ms (profiles/r04_ab_defer.txt) — the immediate reduce reads its slabs hot from the caches
+_WG_ARENA = {}          # (device, stream) -> [chunks, offset]: every deferred contraction keeps its slabs until the flush
+_WG_DEFERRING = [False]
+
+
+def wgrad_defer_reset():
+    """start of a backward: forget reduces an aborted backward may have left behind, rewind the slab arenas"""
+    lib().scat_splitk_reduce_discard()
+    lib().scat_splitk_defer(0)
+    _WG_DEFERRING[0] = False
+    for a in _WG_ARENA.values():
+        a[1] = 0
+
+
+def wgrad_defer(on: bool):
+    """reduces of the weight-gradient calls issued while this is on are recorded, not launched (flush: wgrad_flush)"""
+    on = bool(on) and WG_DEFER and _HAVE_GPU
+    _WG_DEFERRING[0] = on
+    lib().scat_splitk_defer(int(on))
+
+
+def _wgrad_workspace(nbytes, device, slot):
+    if not _WG_DEFERRING[0]:
+        return workspace(nbytes, device, slot)
+    key = (device.type, device.index, _stream())
+    a = _WG_ARENA.setdefault(key, [[], 0])
+    nbytes = (int(nbytes) + 255) // 256 * 256
+    chunks, off = a
+    if not chunks or off + nbytes > chunks[-1].numel():
+        # (the slabs recorded so far live in the older chunks: they stay allocated until the flush)
+        chunks.append(torch.empty(max(nbytes, 256 << 20), dtype=torch.uint8, device=device))
+        off = 0
+    a[1] = off + nbytes
+    return chunks[-1][off:off + nbytes]
+
+
+def wgrad_flush():
+    """one grouped launch (per 48) for every recorded reduce, on the CURRENT stream — the stream the contractions ran on;
+    afterwards the arena of that stream is one chunk large enough for what the stage needed"""
+    if lib().scat_splitk_reduce_pending() > 0:
+        lib().scat_splitk_reduce_flush(_stream())
+    for key, a in _WG_ARENA.items():
+        if len(a[0]) > 1:
+            total = sum(c.numel() for c in a[0])
+            dev = a[0][0].device
+            a[0] = []                                  # (freed blocks are reused stream-ordered behind the flush)
+            if key[2] == _stream():
+                a[0] = [torch.empty(total, dtype=torch.uint8, device=dev)]
+        a[1] = 0
+
+
 def conv2d_wgrad(dy, x, w_shape, stride, pad, in_scale=None, in_shift=None, in_relu=False, out=None,
                  ws_slot="default"):
     _chk(dy, x, in_scale, in_shift, out)
@@ -458,12 +510,12 @@ def conv2d_wgrad(dy, x, w_shape, stride, pad, in_scale=None, in_shift=None, in_r
     if (KH == 7 and KW == 7 and stride == 2 and pad == 3 and Cin == 3 and Cout == 64 and in_scale is None
             and OW % 16 == 0 and OW <= 112 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
             and lib().scat_get_math_mode() == 1 and STEM_SPLIT):
-        ws = workspace(lib().scat_conv7x7_s2_wgrad_split_ws(B, H, W), x.device, ws_slot)
+        ws = _wgrad_workspace(lib().scat_conv7x7_s2_wgrad_split_ws(B, H, W), x.device, ws_slot)
         _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv7x7_s2_wgrad_split, _p(dy), _p(x), _p(dw), B, H, W,
               Cout, _p(ws), ws.numel(), _stream())
         return dw
     need = lib().scat_conv2d_wgrad_ws(B, Cin, H, W, Cout, KH, KW, stride, pad)
-    ws = workspace(need, x.device, ws_slot)
+    ws = _wgrad_workspace(need, x.device, ws_slot)
     _prof(2.0 * B * OH * OW * Cout * Cin * KH * KW, lib().scat_conv2d_wgrad, _p(dy), _p(x), _p(dw), B, Cin, H, W,
           Cout, KH, KW, stride, pad, _p(in_scale), _p(in_shift), int(in_relu), _p(ws), ws.numel(), _stream())
     return dw
@@ -719,7 +771,7 @@ def conv1x1_wgrad_bnb(g, z, coef3, x, w_shape, in_scale=None, in_shift=None, in_
     B, Cin, H, W = x.shape
     Cout = w_shape[0]
     dw = out if out is not None else torch.empty(w_shape, dtype=torch.float32, device=x.device)
-    ws = workspace(lib().scat_conv1x1_wgrad_bnb_ws(B, Cin, H * W, Cout), x.device, ws_slot)
+    ws = _wgrad_workspace(lib().scat_conv1x1_wgrad_bnb_ws(B, Cin, H * W, Cout), x.device, ws_slot)
     _prof(2.0 * B * H * W * Cout * Cin, lib().scat_conv1x1_wgrad_bnb, _p(g), _p(z), _p(coef3), _p(x), _p(dw), B, Cin,
           H * W, Cout, _p(in_scale), _p(in_shift), int(in_relu), _p(ws), ws.numel(), _stream())
     return dw

@@ -32,7 +32,9 @@ def test_header_declares_the_path():
                                                 "scat_set_math_mode",
                                                 # host-side state of the NEXT launch of this thread, no device work
                                                 "scat_epilogue_stats_arm", "scat_epilogue_stats_arm_shift", "scat_epilogue_stats_groups",
-                                                "scat_streamk_arm"):
+                                                "scat_streamk_arm",
+                                                # host-side record of reduces to be flushed later (the flush takes the stream)
+                                                "scat_splitk_defer", "scat_splitk_reduce_pending", "scat_splitk_reduce_discard"):
             assert args[-1][1] == "stream", name
     # every prototype cites the reference file it replaces somewhere in the header
     src = open(os.path.join(ROOT, "include", "scat_hip.h")).read()

@@ -625,7 +625,7 @@ def test_bottleneck_batch96_against_fp64(key, cin, H, stride):
          2e-5 of zero (relative to its largest value), and in fewer than 2e-5 of the elements;
       3. every gradient (dx, dW, dgamma, dbeta) against the fp64 evaluation of the same block WITH THOSE sign patterns
          (relu(z) -> z * mask): no flips left, and the gate is 2e-4 norm-wise maximum — what a wrong reduction grid, a
-         missing 1/N or a misplaced mask would exceed by orders of magnitude."""
+         missing 1/N or a misplaced mask would exceed by orders of magnitude (the gate below is 5e-5: measured 2e-5 at worst)."""
     import json
     import os
     import torch.nn.functional as F
@@ -711,7 +711,7 @@ def test_bottleneck_batch96_against_fp64(key, cin, H, stride):
                 "gradients_max_vs_fp64_with_the_same_signs": rows}
     json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
     worst = max(rows, key=rows.get)
-    assert rows[worst] < 2e-4, (key, worst, rows)
+    assert rows[worst] < 5e-5, (key, worst, rows)       # (measured: 2e-5 at worst — bn1.bias of layer1.0; dx 6e-7 .. 1.2e-6)
     for k, v in blk.named_buffers():
         if "running" in k:
             assert rel_err(v, sd64["b." + k]) < 1e-5, (key, k)

@@ -1401,3 +1401,54 @@ def test_conv1x1_planes_bit_identical(ops, cin, cout, H, B):
     # against the torch op itself
     want = F.conv2d(x.cpu().double(), w.cpu().double()).float()
     assert rel_err(ops.conv1x1_planes(xp, w).cpu(), want) < 2e-5
+
+
+def test_deferred_splitk_reduces(ops):
+    """scat_splitk_defer / scat_splitk_reduce_flush: the fixed-order sums of several weight gradients' split-K slabs as ONE
+    grouped launch.  While deferral is on nothing is written to the outputs (each contraction keeps its slabs in a
+    workspace of its own); the flush produces what the per-call reduces produce (same slabs, a fixed four-way order:
+    1e-6), twice the same bits; a discarded backlog is not performed."""
+    from scat_amd._lib import lib
+    cases = [(64, 64, 1, 1, 28), (64, 256, 1, 1, 28), (128, 128, 3, 1, 14), (256, 64, 1, 1, 28), (128, 128, 3, 2, 28),
+             (64, 64, 3, 1, 56)]
+    B = 8
+    xs, dys, refs = [], [], []
+    for n, (cin, cout, k, s_, H) in enumerate(cases):
+        x = g(t(900 + n, "x", (B, cin, H, H)))
+        OH, _ = ops.conv_out_hw(H, H, k, s_, k // 2)
+        dy = g(t(910 + n, "dy", (B, cout, OH, OH)))
+        xs.append(x), dys.append(dy)
+        refs.append(ops.conv2d_wgrad(dy, x, (cout, cin, k, k), s_, k // 2))
+
+    def deferred():
+        ops.wgrad_defer_reset()
+        outs = []
+        ops.wgrad_defer(True)
+        try:
+            for (cin, cout, k, s_, H), x, dy in zip(cases, xs, dys):
+                out = torch.full((cout, cin, k, k), float("nan"), device=DEV)
+                ops.conv2d_wgrad(dy, x, (cout, cin, k, k), s_, k // 2, out=out)
+                outs.append(out)
+        finally:
+            ops.wgrad_defer(False)
+        return outs
+
+    outs = deferred()
+    npend = lib().scat_splitk_reduce_pending()
+    assert npend >= 4, npend
+    torch.cuda.synchronize()
+    assert sum(bool(torch.isnan(o).all()) for o in outs) == npend       # recorded reduces have not touched their outputs
+    ops.wgrad_flush()
+    assert lib().scat_splitk_reduce_pending() == 0
+    for o, r in zip(outs, refs):
+        assert rel_err(o, r) < 1e-6
+    again = deferred()
+    ops.wgrad_flush()
+    for a, o in zip(again, outs):
+        assert torch.equal(a, o)
+    stale = deferred()
+    ops.wgrad_defer_reset()                                             # an aborted backward: nothing is performed
+    assert lib().scat_splitk_reduce_pending() == 0
+    ops.wgrad_flush()
+    torch.cuda.synchronize()
+    assert sum(bool(torch.isnan(o).all()) for o in stale) == npend
