@@ -242,9 +242,36 @@ def vit_forward(sd, x, prefix, depth=3, heads=8):
     return x
 
 
-def performer_block(sd, x, prefix, emb_s, head):
-    """performer_attn_block.forward in eval mode (dropout off),
-    models/vision_performer.py:34-68. Split order k, q, v (:47)."""
+def hash_dropout_mask(n, p, seed):
+    """The keep mask of the library's Dropout (scat_amd/csrc/misc.hip dropout_kernel, include/scat_hip.h scat_dropout):
+    element e is kept iff u(e) >= p with u the top 24 bits of a splitmix64-style hash of e * 0xD1342543DE82EF95 + seed.
+    The reference's nn.Dropout (models/vision_performer.py:18,28) draws from torch's RNG stream, which no device kernel
+    can replay; this restatement makes the TRAIN-mode values of the performer path checkable against an oracle that uses
+    the same Bernoulli(1 - p) mask, element for element.  -> float64 tensor of 0 / 1."""
+    import numpy as np
+
+    with np.errstate(over="ignore"):
+        z = np.arange(n, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95) + np.uint64(seed)
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return torch.from_numpy((u >= np.float32(p)).astype(np.float64))
+
+
+def performer_block(sd, x, prefix, emb_s, head, dropout_p=0.0):
+    """performer_attn_block.forward, models/vision_performer.py:34-68. Split order k, q, v (:47).
+    dropout_p = 0: eval mode.  dropout_p > 0: train mode (:18 after proj, :28 at the end of the mlp) with the library's
+    hash mask: one 63-bit seed per Dropout call from python ``random``, in call order, as scat_amd.nn.Dropout draws them."""
+    def drop(t):
+        if dropout_p <= 0:
+            return t
+        keep = hash_dropout_mask(t.numel(), dropout_p, random.getrandbits(63)).reshape(t.shape).to(t.dtype)
+        scale = torch.tensor(1.0, dtype=torch.float32) / (torch.tensor(1.0, dtype=torch.float32) - torch.tensor(dropout_p, dtype=torch.float32))
+        return t * keep * scale.to(t.dtype)
+
     emb = emb_s * head
     w = sd[prefix + "w"]
     m = w.shape[0]
@@ -261,10 +288,10 @@ def performer_block(sd, x, prefix, emb_s, head):
         D = (qp * kp.sum(dim=1, keepdim=True)).sum(dim=-1, keepdim=True)  # :49
         kptv = torch.einsum("bin,bim->bnm", v, kp)  # :50
         outs.append(torch.einsum("bti,bni->btn", qp, kptv) / D)  # :52
-    x = x + F.linear(torch.cat(outs, dim=-1), sd[prefix + "proj.weight"], sd[prefix + "proj.bias"])
+    x = x + drop(F.linear(torch.cat(outs, dim=-1), sd[prefix + "proj.weight"], sd[prefix + "proj.bias"]))
     h = F.layer_norm(x, (emb,), sd[prefix + "ln2.weight"], sd[prefix + "ln2.bias"], LN_EPS)
     h = F.gelu(F.linear(h, sd[prefix + "mlp.0.weight"], sd[prefix + "mlp.0.bias"]))
-    return x + F.linear(h, sd[prefix + "mlp.2.weight"], sd[prefix + "mlp.2.bias"])
+    return x + drop(F.linear(h, sd[prefix + "mlp.2.weight"], sd[prefix + "mlp.2.bias"]))
 
 
 def vip_forward(sd, mean_params, x, heads, emb_s, depth=3, iteration=3, patch=4):

@@ -525,6 +525,16 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
     const int mt = (d.M + BM - 1) / BM, nt = (d.npix + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, mt * nt);
     const int nstage = d.ntap * ((d.C + PW_KS - 1) / PW_KS);
+    if constexpr (kDiag) {
+        // tools build, SCAT_TUNE = 300 + t: the workgroups of the second / third residency slot of a CU (block index / 256)
+        // start t / 2t microseconds late, so that the co-resident tiles' prologues and epilogues stop coinciding
+        if (d.variant >= 300 && d.variant < 400) {
+            const int slot = (blockIdx.x >> 8) % 3;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+            const unsigned long long wait = (unsigned long long)slot * (d.variant - 300) * 100ull;
+            while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     pw_split_tile<WM, BN, TF, DS, STEM, PL>(d, dc, tile, 0, nstage, [](auto&) { return true; });
 }
 

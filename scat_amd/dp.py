@@ -401,7 +401,13 @@ def init_distributed():
         if torch.cuda.is_available() and backend == "nccl":
             # the queue plan is verified, not trusted: did the communicator take the stream left for it, and do the
             # step's heavy streams still sit on queues of their own (re-picked / warned about otherwise)
-            streams.verify_collective_plan(torch.device("cuda", local))
+            try:
+                streams.verify_collective_plan(torch.device("cuda", local))
+            except Exception as e:   # noqa: BLE001 - the check is advisory: it must never cost a run its process group
+                import warnings
+
+                warnings.warn(f"scat_amd.dp: the hardware-queue plan could not be verified ({e!r}); continuing",
+                              RuntimeWarning)
     return rank, local, world
 
 

@@ -418,6 +418,43 @@ def test_performer_block_golden(golden):
             assert digest_err(digest(p.grad, 8), g["g:" + k]) < 1e-4, k
 
 
+def test_performer_block_train_mode_values():
+    """BASELINE configs[4] in TRAIN mode, value for value (VERDICT r03 "missing" 5; models/vision_performer.py:18,28: the
+    two Dropout(0.1) of a block are active whenever the module trains).  The reference draws its masks from torch's RNG
+    stream, which a device kernel cannot replay; the library's masks come from a counter hash seeded from python
+    ``random`` (scat_dropout), and the oracle restates that hash (oracle.hash_dropout_mask) — so with the same ``random``
+    seed both sides drop the SAME elements and the train-mode forward, input gradient and every parameter gradient can
+    be compared at the eval-mode tolerances, in fp64 on the oracle side."""
+    from scat_amd.models import vision_performer as P
+
+    blk = P.performer_attn_block(49, 16)
+    state = synth.to_torch(synth.performer_state(91, ""))
+    blk.load_state_dict(state, strict=True)
+    blk.cuda().train()
+    x = T(synth.normal_like(92, "x", (2, 21, 784), std=0.5))
+    cot = T(synth.normal_like(93, "cot", (2, 21, 784)))
+    sd = {k: v.double().requires_grad_(k != "w") for k, v in state.items()}
+    xr = x.double().requires_grad_(True)
+    random.seed(77)
+    yr = O.performer_block(sd, xr, "", 49, 16, dropout_p=0.1)
+    (yr * cot.double()).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    random.seed(77)
+    y = blk(xg)
+    dropped = float((O.hash_dropout_mask(x.numel(), 0.1, 12345) == 0).double().mean())
+    assert 0.08 < dropped < 0.12                              # Bernoulli(0.9) keep mask
+    assert rel_err(y, yr.detach()) < 2e-5, rel_err(y, yr.detach())
+    (y * cot.cuda()).sum().backward()
+    assert rel_err(xg.grad, xr.grad) < 5e-5
+    for k, p in blk.named_parameters():
+        if p.requires_grad:
+            assert rel_err(p.grad, sd[k].grad) < 1e-4, k
+    # and the eval-mode path of the same oracle function is the golden-pinned one (dropout_p = 0 changes nothing)
+    with torch.no_grad():
+        assert torch.equal(O.performer_block({k: v.detach() for k, v in sd.items()}, x.double(), "", 49, 16),
+                           O.performer_block({k: v.detach() for k, v in sd.items()}, x.double(), "", 49, 16, 0.0))
+
+
 def test_vip_golden(golden):
     from scat_amd.models.vision_performer import ViP
 

@@ -1409,6 +1409,15 @@ def test_deferred_splitk_reduces(ops):
     workspace of its own); the flush produces what the per-call reduces produce (same slabs, a fixed four-way order:
     1e-6), twice the same bits; a discarded backlog is not performed."""
     from scat_amd._lib import lib
+    saved, ops.WG_DEFER = ops.WG_DEFER, True          # (off by default: measured slower on the step, DESIGN 1d)
+    try:
+        _deferred_splitk_reduces(ops, lib)
+    finally:
+        ops.WG_DEFER = saved
+        ops.wgrad_defer_reset()
+
+
+def _deferred_splitk_reduces(ops, lib):
     cases = [(64, 64, 1, 1, 28), (64, 256, 1, 1, 28), (128, 128, 3, 1, 14), (256, 64, 1, 1, 28), (128, 128, 3, 2, 28),
              (64, 64, 3, 1, 56)]
     B = 8
