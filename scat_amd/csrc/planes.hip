@@ -60,7 +60,7 @@ __device__ __forceinline__ void wait_vm() {
 // everything of stage s has landed, LA - 1 younger stages stay in flight.  Loads past the last stage are issued with an
 // out-of-range offset (the bounds check drops them) so that the counts never change.
 // DIAG (tools build only, results wrong): 1 = no activation DMA, 2 = no weight loads, 4 = no MFMAs, 8 = no output stores,
-// 16 = no stage barrier, 32 = one LDS fragment read per stage instead of 24
+// 16 = no stage barrier, 32 = one LDS fragment read per stage instead of 24; 64 (results RIGHT) = the loads spread over the stage
 template <int WM, int BN, int NB, int DIAG = 0>
 __global__ __launch_bounds__(NT, (NB == 2 ? 3 : 2)) void pw_planes_kernel(PlDesc d, OutDesc dc) {
     constexpr int BM = 32 * WM, WN = 4 / WM, NI = BN / (32 * WN);
@@ -101,29 +101,29 @@ __global__ __launch_bounds__(NT, (NB == 2 ? 3 : 2)) void pw_planes_kernel(PlDesc
         psoff[i] = (int)((uint32_t)plane * d.pstride) + oct * d.HW * 16;
         plds[i] = (uint32_t)(((plane * 4 + oct) * BN + (i % H) * 64) * 16);
     }
+    auto issue_b1 = [&](int st, int buf, auto i_tag) {        // piece i of stage st
+        constexpr int i = decltype(i_tag)::value;
+        const uint32_t la = lds0 + (uint32_t)buf * (BUF * 16) + plds[i];
+        const int vo = st < nstage ? voff[i % H] : OOB, so = psoff[i] + st * stage_soff;
+        if constexpr (DIAG & 1) asm volatile("" :: "s"(la), "v"(vo), "s"(so));
+        else dma16(rs_b, la, vo, so);
+    };
     auto issue_b = [&](int st, int buf) {
-        const bool live = st < nstage;
-        const uint32_t base = lds0 + (uint32_t)buf * (BUF * 16);
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            if constexpr (DIAG & 1) asm volatile("" :: "s"(base + plds[i]), "v"(live ? voff[i % H] : OOB), "s"(psoff[i] + st * stage_soff));
-            else dma16(rs_b, base + plds[i], live ? voff[i % H] : OOB, psoff[i] + st * stage_soff);
-        }
+        static_for<PPW>([&](auto i_tag) { issue_b1(st, buf, i_tag); });
     };
 
     // ---- weights: lane (row, h) takes 16 bytes per plane and 16-channel sub-chunk
     const int row = i0 + wm * 32 + l31;
     const int aoff = row < d.M ? row * 32 + lh * 16 : OOB;
     const int aplane = d.M * 32;
-    auto issue_a = [&](u32x4 (&dst)[2][3], int st) {
+    auto issue_a1 = [&](u32x4 (&dst)[2][3], int st, auto k_tag) {      // load k = 3 t + p of stage st
+        constexpr int t = decltype(k_tag)::value / 3, p = decltype(k_tag)::value % 3;
         const int vo = st < nstage ? aoff : OOB;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                if constexpr (DIAG & 2) dst[t][p] = u32x4{(uint32_t)vo, 0x3f803f80u, (uint32_t)(st + t + p), 0x3f803f80u};
-                else aload16(dst[t][p], rs_a, vo, ((2 * st + t) * 3 + p) * aplane);
-            }
+        if constexpr (DIAG & 2) dst[t][p] = u32x4{(uint32_t)vo, 0x3f803f80u, (uint32_t)(st + t + p), 0x3f803f80u};
+        else aload16(dst[t][p], rs_a, vo, ((2 * st + t) * 3 + p) * aplane);
+    };
+    auto issue_a = [&](u32x4 (&dst)[2][3], int st) {
+        static_for<6>([&](auto k_tag) { issue_a1(dst, st, k_tag); });
     };
 
     f32x16 acc[1][NI];
@@ -159,13 +159,26 @@ __global__ __launch_bounds__(NT, (NB == 2 ? 3 : 2)) void pw_planes_kernel(PlDesc
         if constexpr (!(DIAG & 16)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        issue_a(areg[NXT], s + LA);
-        issue_b(s + LA, NXT);
+        if constexpr (!(DIAG & 64)) {
+            issue_a(areg[NXT], s + LA);
+            issue_b(s + LA, NXT);
+        }
         const u32x4* bcur = B0 + CUR * BUF;
         read_b(bfr[0], bcur, 0, 0);
         static_for<2 * NI>([&](auto i_tag) {
             constexpr int I = decltype(i_tag)::value, t = I / NI, b = I % NI;
             constexpr int fcur = I & 1, fnxt = fcur ^ 1;
+            if constexpr (DIAG & 64) {
+                // the same 6 + PPW vector-memory instructions in the same order, spread over the stage's MFMA groups
+                // instead of issued as one burst behind the barrier
+                constexpr int NG = 2 * NI, TOT = 6 + PPW;
+                constexpr int lo = I * TOT / NG, hi = (I + 1) * TOT / NG;
+                static_for<hi - lo>([&](auto q_tag) {
+                    constexpr int q = lo + decltype(q_tag)::value;
+                    if constexpr (q < 6) issue_a1(areg[NXT], s + LA, std::integral_constant<int, q>{});
+                    else issue_b1(s + LA, NXT, std::integral_constant<int, q - 6>{});
+                });
+            }
             if constexpr (DIAG & 32) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) bfr[fnxt][q] = bfr[fcur][q];
@@ -334,6 +347,7 @@ extern "C" int scat_conv1x1_planes(const void* planes, const float* w, float* ds
         case 16: launch_pw_planes<4, 128, 2, 16>(d, dc, st); break;
         case 32: launch_pw_planes<4, 128, 2, 32>(d, dc, st); break;
         case 59: launch_pw_planes<4, 128, 2, 59>(d, dc, st); break;
+        case 64: launch_pw_planes<4, 128, 2, 64>(d, dc, st); break;
         default: launch_pw_planes<4, 128, 2, 0>(d, dc, st);
         }
         SCAT_LAUNCH_CHECK("scat_conv1x1_planes");

@@ -12,7 +12,7 @@ from scat_amd import ops  # noqa: E402
 from tools.planes_bench import bench  # noqa: E402
 
 SHAPES = [(512, 256, 28), (256, 1024, 14), (1024, 512, 14), (128, 512, 28), (2048, 512, 7)]
-VARIANTS = [("full", 100), ("no DMA", 101), ("no weight loads", 102), ("no loads", 103), ("no MFMA", 104),
+VARIANTS = [("full", 100), ("loads spread", 164), ("no DMA", 101), ("no weight loads", 102), ("no loads", 103), ("no MFMA", 104),
             ("no stores", 108), ("no loads/stores", 111), ("no barrier", 116), ("no LDS reads", 132),
             ("MFMA only (no loads/stores/barrier/LDS reads)", 159)]
 
@@ -28,9 +28,11 @@ def main():
         wp = ops.WeightPrep()
         ops.conv2d_fwd(x, w, 1, 0, wp=wp)
         wp.run(True)
+        y0 = ops.conv1x1_planes(xp, w, wp=wp, lds_stages=100).clone()
+        same = torch.equal(ops.conv1x1_planes(xp, w, wp=wp, lds_stages=164), y0)
         fns = [(lambda c=c: ops.conv1x1_planes(xp, w, out=y, wp=wp, lds_stages=c)) for _, c in VARIANTS]
         us = bench(fns, 5, 5)
-        print(f"{cin}->{cout}@{H}".ljust(20) + "".join(f"{u:17.1f}" for u in us), flush=True)
+        print(f"{cin}->{cout}@{H}".ljust(20) + "".join(f"{u:17.1f}" for u in us) + f"   spread == full: {same}", flush=True)
 
 
 if __name__ == "__main__":
