@@ -42,9 +42,11 @@ __device__ __forceinline__ i32x4 make_srd(const void* p, uint32_t bytes) {
     return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
 // 64 lanes x 16 bytes from base + voff + soff into LDS at lds_addr + 16 * lane
+// (M0 holds the LDS destination; it is compiler-reserved, so the statement saves and restores it: cdna_hip_programming.md 5.7)
 __device__ __forceinline__ void dma16(const i32x4 rs, const uint32_t lds_addr, const int voff, const int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void aload16(u32x4& dst, const i32x4 rs, const int voff, const int soff) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
