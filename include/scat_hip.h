@@ -299,6 +299,8 @@ int scat_subsample2(const float* x, float* y, int B, int C, int H, int W, void* 
 int scat_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                        int rows, int dim, float eps, void* stream);
 int64_t scat_layernorm_bwd_ws(int rows, int dim);
+/* dgamma == dbeta == NULL: the input gradient only (no parameter sums, ws unused) — the pose-length term's replay,
+ * models/hand_net.py:396 */
 int scat_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx, float* dgamma, float* dbeta, int rows, int dim, void* ws, int64_t ws_bytes,
                        void* stream);
@@ -338,6 +340,15 @@ int scat_colsum(const float* x, float* out, int rows, int cols, int accumulate, 
  * models/vit.py:40-47 at HRNet's 24 672 x 196 tokens) */
 int64_t scat_colsum_ws(int rows, int cols);
 int scat_colsum_sliced(const float* x, float* out, int rows, int cols, int accumulate, void* ws, int64_t ws_bytes, void* stream);
+/* n <= 16 independent column sums as ONE launch, each summed in scat_colsum's order (bit-identical to n calls): the bias
+ * gradients of a token mixer's backward (to_out and the two FeedForward Linears of every layer,
+ * models/vision_transformer.py:33-35,57).  `jobs` is a HOST array. */
+typedef struct ScatColsumJob {
+    const float* x;
+    float* out;
+    int rows, cols, accumulate;
+} ScatColsumJob;
+int scat_colsum_group(const ScatColsumJob* jobs, int n, void* stream);
 /* tokens: y[B,T,D] = x[B,T,D] + pe[T,D], then rows t in masked[] <- mask_token[D]   (hand_net.py:366-373) */
 int scat_tokens_fwd(const float* x, const float* pe, const float* mask_token, const int32_t* masked, int nmasked,
                     float* y, int B, int T, int D, void* stream);

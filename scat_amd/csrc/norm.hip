@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// dx per row; t = dy * xhat written for the dgamma column sum
+// dx per row; t = dy * xhat written for the dgamma column sum (t == nullptr: the input gradient only)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
@@ -857,17 +857,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int i = lane; i < dim; i += 64) {
         float d = dy[off + i], xh = (x[off + i] - mu) * rs;
         dx[off + i] = rs * (d * gamma[i] - a - xh * b);
-        t[off + i] = d * xh;
+        if (t) t[off + i] = d * xh;
     }
 }
 
 // out[j] (+)= sum_i x[i*cols + j]; block = 16 columns x 64 row lanes (many blocks, short loops, 8 loads in
 // flight per thread), fixed summation order
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows,
-                                                      int cols, int accumulate) {
+__device__ __forceinline__ void colsum_block(const float* __restrict__ x, float* __restrict__ out, int rows, int cols,
+                                             int accumulate, int bx) {
     __shared__ float sh[64][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int j = blockIdx.x * 16 + tx;
+    const int j = bx * 16 + tx;
     float s = 0.f;
     if (j < cols) {
         int i = ty;
@@ -887,6 +887,24 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
         __syncthreads();
     }
     if (ty == 0 && j < cols) out[j] = (accumulate ? out[j] : 0.f) + sh[0][tx];
+}
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows,
+                                                      int cols, int accumulate) {
+    colsum_block(x, out, rows, cols, accumulate, blockIdx.x);
+}
+// several independent column sums (the bias gradients of a token mixer's backward, LayerNorm's d-gamma / d-beta pair) as ONE
+// launch: blockIdx.y = the job, each job summed exactly as colsum_kernel sums it
+constexpr int CSG_MAX = 16;
+struct ColsumJobs {
+    const float* x[CSG_MAX];
+    float* out[CSG_MAX];
+    int rows[CSG_MAX], cols[CSG_MAX], acc[CSG_MAX];
+};
+__global__ __launch_bounds__(1024) void colsum_group_kernel(ColsumJobs J) {
+    const int q = blockIdx.y;
+    const int cols = J.cols[q];
+    if ((int)blockIdx.x * 16 >= cols) return;
+    colsum_block(J.x[q], J.out[q], J.rows[q], cols, J.acc[q], blockIdx.x);
 }
 
 }  // namespace scat
@@ -1231,12 +1249,18 @@ extern "C" int64_t scat_layernorm_bwd_ws(int rows, int dim) {
 extern "C" int scat_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int dim,
                                   void* ws, int64_t ws_bytes, void* stream) {
-    SCAT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, SCAT_E_ARG,
+    SCAT_REQUIRE(dy && x && gamma && mean && rstd && dx && (!dgamma == !dbeta), SCAT_E_ARG,
                  "scat_layernorm_bwd: null pointer");
     SCAT_REQUIRE(rows > 0 && dim > 0, SCAT_E_SHAPE, "scat_layernorm_bwd: non-positive dimension");
+    hipStream_t st = (hipStream_t)stream;
+    if (!dgamma) {      // the input gradient only (the pose-length term's replay of the tape): no parameter sums, no workspace
+        hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, (float*)nullptr,
+                           rows, dim);
+        SCAT_LAUNCH_CHECK("scat_layernorm_bwd");
+        return SCAT_OK;
+    }
     SCAT_REQUIRE(ws && ws_bytes >= scat_layernorm_bwd_ws(rows, dim), SCAT_E_WORKSPACE,
                  "scat_layernorm_bwd: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
     float* t = (float*)ws;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, t, rows,
                        dim);
@@ -1247,8 +1271,10 @@ extern "C" int scat_layernorm_bwd(const float* dy, const float* x, const float* 
                            dim, cdiv(rows, S));
         hipLaunchKernelGGL(colsum2_fin_kernel, dim3(cdiv(dim, 256)), dim3(256), 0, st, (const float*)part, dgamma, dbeta, S, dim, 0);
     } else {
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim, 16)), dim3(1024), 0, st, (const float*)t, dgamma, rows, dim, 0);
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim, 16)), dim3(1024), 0, st, dy, dbeta, rows, dim, 0);
+        ColsumJobs J = {};
+        J.x[0] = t; J.out[0] = dgamma; J.x[1] = dy; J.out[1] = dbeta;
+        J.rows[0] = J.rows[1] = rows; J.cols[0] = J.cols[1] = dim;
+        hipLaunchKernelGGL(colsum_group_kernel, dim3(cdiv(dim, 16), 2), dim3(1024), 0, st, J);
     }
     SCAT_LAUNCH_CHECK("scat_layernorm_bwd");
     return SCAT_OK;
@@ -1282,5 +1308,21 @@ extern "C" int scat_colsum(const float* x, float* out, int rows, int cols, int a
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 16)), dim3(1024), 0, (hipStream_t)stream, x, out, rows, cols,
                        accumulate);
     SCAT_LAUNCH_CHECK("scat_colsum");
+    return SCAT_OK;
+}
+
+// n <= 16 independent column sums, one launch; each is summed in scat_colsum's order (bit-identical to n calls)
+extern "C" int scat_colsum_group(const ScatColsumJob* jobs, int n, void* stream) {
+    SCAT_REQUIRE(jobs && n > 0 && n <= CSG_MAX, SCAT_E_ARG, "scat_colsum_group: 1..16 jobs");
+    ColsumJobs J = {};
+    int maxc = 0;
+    for (int q = 0; q < n; ++q) {
+        SCAT_REQUIRE(jobs[q].x && jobs[q].out && jobs[q].rows > 0 && jobs[q].cols > 0, SCAT_E_ARG, "scat_colsum_group: bad job");
+        J.x[q] = jobs[q].x; J.out[q] = jobs[q].out; J.rows[q] = jobs[q].rows; J.cols[q] = jobs[q].cols;
+        J.acc[q] = jobs[q].accumulate;
+        maxc = max(maxc, jobs[q].cols);
+    }
+    hipLaunchKernelGGL(colsum_group_kernel, dim3(cdiv(maxc, 16), n), dim3(1024), 0, (hipStream_t)stream, J);
+    SCAT_LAUNCH_CHECK("scat_colsum_group");
     return SCAT_OK;
 }

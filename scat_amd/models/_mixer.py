@@ -134,6 +134,15 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
         else:
             group.append((slot, dy2d, x2d))
 
+    # ... and so are the bias gradients (three column sums per layer)
+    bias_group = [] if group is not None else None
+
+    def bgrad(slot, dy2d):
+        if bias_group is None:
+            grads[slot] = pgrad(lambda: ops.colsum(dy2d), dy2d)
+        else:
+            bias_group.append((slot, dy2d))
+
     def pgrad(fn, *inputs):
         if side is None:
             return fn()
@@ -162,14 +171,14 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
         da = ops.linear_dgrad(d, w2)
         if want_param_grads:
             wgrad(pi + kf + 2, d, a)
-            grads[pi + kf + 3] = pgrad(lambda d=d: ops.colsum(d), d)
+            bgrad(pi + kf + 3, d)
         du = ops.gelu_bwd(da, u)
         if want_param_grads:
             wgrad(pi + kf, du, h2)
-            grads[pi + kf + 1] = pgrad(lambda du=du: ops.colsum(du), du)
+            bgrad(pi + kf + 1, du)
         dh2 = ops.linear_dgrad(du, w0)
         if cfg.ff_ln:
-            dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, p[kn], mu2, rs2)
+            dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, p[kn], mu2, rs2, want_param_grads)
             if want_param_grads:
                 grads[pi + kn], grads[pi + kn + 1] = dg2, db2
         else:
@@ -178,14 +187,14 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
             dx1 = ops.axpy(dx1, d, 1.0, out=dx1)
         # ---- attention: x1 = x + ao·Woutᵀ + b   (post_ln: x1 = x + LN(ao·Woutᵀ + b))
         if cfg.post_ln:
-            da1, dgp, dbp = ops.layernorm_bwd(dx1, a1, p[kp], mup, rsp)
+            da1, dgp, dbp = ops.layernorm_bwd(dx1, a1, p[kp], mup, rsp, want_param_grads)
             if want_param_grads:
                 grads[pi + kp], grads[pi + kp + 1] = dgp, dbp
         else:
             da1 = dx1
         if want_param_grads:
             wgrad(pi + k + 1, da1, ao.view(M, inner))
-            grads[pi + k + 2] = pgrad(lambda da1=da1: ops.colsum(da1), da1)
+            bgrad(pi + k + 2, da1)
         dao = ops.linear_dgrad(da1, wout)
         dqkv = ops.attention_bwd(dao.view(B, n, inner), qkv.view(B, n, 3 * inner), attn, cfg.heads, cfg.dim_head,
                                  cfg.scale).view(M, 3 * inner)
@@ -193,7 +202,7 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
             wgrad(pi + k, dqkv, h)
         dh = ops.linear_dgrad(dqkv, wqkv)
         if cfg.ln1:
-            dx, dg1, db1 = ops.layernorm_bwd(dh, cur, p[0], mu1, rs1)
+            dx, dg1, db1 = ops.layernorm_bwd(dh, cur, p[0], mu1, rs1, want_param_grads)
             if want_param_grads:
                 grads[pi], grads[pi + 1] = dg1, db1
         else:
@@ -203,6 +212,11 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
         pairs = [(dy2d, x2d) for _, dy2d, x2d in group]
         outs = pgrad(lambda: ops.linear_wgrad_group(pairs), *[t for pr in pairs for t in pr])
         for (slot, _, _), g in zip(group, outs):
+            grads[slot] = g
+    if bias_group:
+        xs = [t for _, t in bias_group]
+        outs = pgrad(lambda: ops.colsum_group(xs), *xs)
+        for (slot, _), g in zip(bias_group, outs):
             grads[slot] = g
     if side is not None:
         main.wait_stream(side)

@@ -633,6 +633,30 @@ def colsum(x2d, out=None, accumulate=False):
     return o
 
 
+class _ColsumJob(ctypes.Structure):
+    """include/scat_hip.h ScatColsumJob"""
+    _fields_ = [("x", ctypes.c_void_p), ("out", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
+                ("accumulate", ctypes.c_int)]
+
+
+def colsum_group(xs):
+    """[x2d, ...] -> [column sums] with one launch per 16 (scat_colsum_group; bit-identical to colsum on each)"""
+    outs = []
+    for i0 in range(0, len(xs), GROUP_MAX):
+        chunk = xs[i0:i0 + GROUP_MAX]
+        if any(lib().scat_colsum_ws(*x.shape) > 0 for x in chunk):      # tall inputs keep their sliced two-launch form
+            outs += [colsum(x) for x in chunk]
+            continue
+        arr = (_ColsumJob * len(chunk))()
+        for q, x in enumerate(chunk):
+            _chk(x)
+            o = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+            outs.append(o)
+            arr[q] = _ColsumJob(_p(x), _p(o), x.shape[0], x.shape[1], 0)
+        lib().scat_colsum_group(arr, len(chunk), _stream())
+    return outs
+
+
 # ---------------------------------------------------------------- BatchNorm
 
 def bn_train_stats(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
@@ -833,10 +857,15 @@ def layernorm_fwd(x2d, gamma, beta, eps=1e-5):
     return y, st[0], st[1]
 
 
-def layernorm_bwd(dy2d, x2d, gamma, mean, rstd):
+def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, want_params=True):
+    """-> (dx, dgamma, dbeta); want_params=False: (dx, None, None) without the parameter sums"""
     _chk(dy2d, x2d, gamma, mean, rstd)
     rows, dim = x2d.shape
     dx = torch.empty_like(x2d)
+    if not want_params:
+        lib().scat_layernorm_bwd(_p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(dx), None, None, rows, dim, None, 0,
+                                 _stream())
+        return dx, None, None
     dg = torch.empty((2, dim), dtype=torch.float32, device=x2d.device)
     ws = workspace(lib().scat_layernorm_bwd_ws(rows, dim), x2d.device)
     lib().scat_layernorm_bwd(_p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg[0]), _p(dg[1]), rows,

@@ -714,6 +714,9 @@ def test_layernorm(ops, rows, dim):
     assert rel_err(yg, y) < 1e-5
     dxg, dgg, dbg = ops.layernorm_bwd(g(dy), g(x.detach()), g(gm.detach()), mean, rstd)
     assert rel_err(dxg, dx) < 1e-5 and rel_err(dgg, dg) < 1e-5 and rel_err(dbg, db) < 1e-5
+    # the input gradient alone (the pose-length term's replay, hand_net.py:396): same bits, no parameter sums
+    dx_only, none_g, none_b = ops.layernorm_bwd(g(dy), g(x.detach()), g(gm.detach()), mean, rstd, want_params=False)
+    assert none_g is None and none_b is None and torch.equal(dx_only, dxg)
 
 
 @pytest.mark.parametrize("B,n,heads", [(4, 21, 8), (2, 128, 8), (3, 65, 2), (2, 21, 16), (3, 64, 3), (2, 96, 5),
@@ -1273,6 +1276,18 @@ def test_colsum_tall(ops, rows, cols):
     acc = g(torch.ones(cols))
     ops.colsum(g(x), out=acc, accumulate=True)
     assert rel_err(acc, ref + 1.0) < 2e-6
+
+
+def test_colsum_group(ops):
+    """the bias gradients of a token mixer's backward as one launch (scat_colsum_group): bit for bit what one scat_colsum
+    per matrix gives, for ragged shapes, more than 16 jobs, and a tall matrix in the list (which keeps its sliced form)"""
+    shapes = [(2016, 392), (2016, 784), (2016, 3), (77, 1), (5, 1090), (2016, 196)] * 3 + [(24672, 196)]
+    xs = [g(t(410 + i, "x", sh) + 0.1 * i) for i, sh in enumerate(shapes)]
+    got = ops.colsum_group(xs)
+    assert len(got) == len(xs)
+    for x, o in zip(xs, got):
+        assert o.shape == (x.shape[1],) and torch.equal(o, ops.colsum(x))
+        assert rel_err(o, x.double().sum(0)) < 2e-6
 
 
 @pytest.mark.parametrize("B,C,H", [(96, 256, 14), (96, 64, 7), (5, 128, 14), (3, 70, 9)])
