@@ -118,7 +118,8 @@ def mixer_backward(tape: Tape, dy: torch.Tensor, want_param_grads: bool = True):
     # backward: they run on the backbone's side stream next to the data-gradient chain, whose kernels (M = 2016
     # tokens) are far too small to fill the GPU on their own.  Joined before the node returns.
     main = side = None
-    if want_param_grads and d.is_cuda and _sw.ab("SCAT_SIDE_HEAD", True):
+    from .. import graphed
+    if want_param_grads and d.is_cuda and _sw.ab("SCAT_SIDE_HEAD", True) and graphed.fork_ok():
         from . import resnet as _rn
 
         side = _rn._side_stream(d.device, "tokens")

@@ -194,6 +194,20 @@ FUSED_CBR = _sw.ab("SCAT_HRNET_FUSED_CBR", True)   # conv + BatchNorm + ReLU uni
 EPI_STATS_CBR = _sw.ab("SCAT_HRNET_CBR_EPI", True)   # ... with the BatchNorm sums from the convolution epilogue
 FUSED_BOTTLENECK = _sw.ab("SCAT_HRNET_FUSED_L1", True)   # layer1's Bottlenecks on ResNet's block executor
 PARALLEL_BRANCHES = _sw.ab("SCAT_HRNET_PAR", True)   # one stream per resolution branch of a stage
+STAR_EXCHANGE = _sw.ab("SCAT_HRNET_STAR", True)   # the exchange's barrier through the caller's stream + relay nodes
+
+
+class _RelayFn(torch.autograd.Function):
+    """The same tensor as a node of the CALLER's stream (no kernel in either direction): autograd then orders a branch
+    stream against the caller's stream only, never against another branch's (StageModule.forward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 def _branch_stream(device, i):
@@ -334,14 +348,33 @@ class StageModule(nn.Module):
                 outs[i] = self.branches[i](x[i])
             if i:
                 x[i].record_stream(sts[i])
+        # every exchange output reads every branch: a barrier.  Routed through the caller's stream (it waits for the
+        # branches, the branches then wait for it) rather than branch-to-branch: the same ordering, and a stream
+        # capture's fork / join graph stays a star around the capturing stream (hipStreamEndCapture does not survive
+        # side streams that wait on each other).  Autograd replays each node on its forward's stream and orders producer
+        # and consumer streams itself, so a branch output that another branch's stream reads passes through a relay node
+        # on the caller's stream: in the backward, too, the branch streams only ever meet the caller's.
+        relay = list(outs)
+        if STAR_EXCHANGE:
+            for j in range(1, n):
+                main.wait_stream(sts[j])
+            for j in range(1, n):
+                relay[j] = _RelayFn.apply(outs[j])
         fused = [None] * nout
         for i in range(nout - 1, -1, -1):
+            if STAR_EXCHANGE:
+                if i:
+                    sts[i].wait_stream(main)
+            else:                      # (A/B runs: every exchange stream waits for every other branch's stream directly)
+                for j in range(n):
+                    if j != i:
+                        sts[i].wait_stream(sts[j])
+            srcs = [outs[j] if j == i else relay[j] for j in range(n)]
             for j in range(n):
                 if j != i:
-                    sts[i].wait_stream(sts[j])
                     outs[j].record_stream(sts[i])
             with torch.cuda.stream(sts[i]):
-                fused[i] = self._fuse(i, outs)
+                fused[i] = self._fuse(i, srcs)
         for i in range(1, max(n, nout)):
             main.wait_stream(sts[i])
         for i in range(1, nout):
