@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence: everything that ends up under profiles/r03_* (run on the GPU box, outputs in gpurun_out/)
+# Per-round evidence: everything that ends up under profiles/rNN_* (run on the GPU box, outputs in gpurun_out/)
 set -u
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the copy of the repository there)}"
 cd "$GRAFT_REPO_ROOT"
@@ -22,12 +22,18 @@ prof() {
   python3 tools/prof_summary.py $f auto 90 > $O/${R}_bench_kernel_summary_$name.txt 2>&1
   cp $f $O/${R}_bench_kernel_stats_$name.csv
   t=$(find $O/prof_$name -name 'run_kernel_trace.csv' | head -1)
-  python3 tools/trace_gaps.py $t 8 > $O/${R}_trace_gaps_$name.txt 2>&1
+  python3 tools/trace_gaps.py $t 8 60 > $O/${R}_trace_gaps_$name.txt 2>&1
   head -2 $O/${R}_bench_kernel_summary_$name.txt
   rm -rf $O/prof_$name
 }
 prof default A=1
 prof serialized SCAT_DIAG=1 SCAT_SIDE_WGRAD=0 SCAT_OVERLAP_TOKENS=0 SCAT_EARLY_ADAM=0
+echo "[profiles] hrnet kernel stats"
+rm -rf $O/prof_hr
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_hr -o run -- $B --config hrnet_w32 --steps 8 --warmup 4 --no-cpu-baseline --no-roofline > $O/prof_hr.log 2>&1 )
+python3 tools/trace_gaps.py $(find $O/prof_hr -name 'run_kernel_trace.csv' | head -1) 4 70 > $O/${R}_hrnet_trace_gaps_default.txt 2>&1
+head -1 $O/${R}_hrnet_trace_gaps_default.txt
+rm -rf $O/prof_hr
 echo "[profiles] traffic"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$c
