@@ -271,6 +271,20 @@ int scat_bn_bwd_pre(float* dy_g, const float* dy_add, const float* x, const floa
                     const float* shift, const float* save_mean, const float* save_invstd, const float* gamma,
                     float* dgamma, float* dbeta, float* coef3, int B, int C, int HW, void* ws, int64_t ws_bytes,
                     void* stream);
+/* The reduction of that first half inside the kernel that COMPLETES the gradient (models/resnet.py:93-96: the gradient of a
+ * block output is the next block's conv1 data gradient accumulated onto the shortcut's gradient): armed before an
+ * accumulating scat_conv1x1_s1 call, the kernel — if it is one that can (128-row tiles on split products; others ignore it)
+ * — masks the completed gradient with the output's sign bits `mask` (scat_bn_apply's mask_out), stores the MASKED gradient
+ * and leaves per channel and column group the sums of g and g * (x - mean[c]) in `part` ([C][groups][2] floats; bytes >=
+ * C * (ceil(B*HW / 32) + 4) * 8 always suffices).  x: the raw output of the convolution in front of that BatchNorm, n floats
+ * (= the size of the gradient tensor).  scat_epilogue_bnb_groups() right after the call returns the number of groups written
+ * (0: not done, use scat_bn_bwd_pre) and disarms; scat_bn_bwd_pre_partials finishes coef3 / dgamma / dbeta from them.  Same
+ * host-thread, one-shot protocol as scat_epilogue_stats_arm. */
+int scat_epilogue_bnb_arm(const float* x, const uint8_t* mask, const float* mean, int64_t n, float* part, int64_t part_bytes);
+int scat_epilogue_bnb_groups(void);
+int scat_bn_bwd_pre_partials(const float* partials, int groups, int B, int C, int HW, const float* save_mean,
+                             const float* save_invstd, const float* gamma, float* dgamma, float* dbeta, float* coef3,
+                             void* stream);
 /* dx[B,Cin,HW] (+)= w^T . (ca*g + cb*z + cc): data gradient of a 1x1 conv whose output gradient is the BatchNorm
  * backward above (g, coef3 from scat_bn_bwd_pre; z = the conv's raw output).  ws: scat_conv1x1_s1_ws(Cin, Cout). */
 int scat_conv1x1_s1_bnb(const float* g, const float* z, const float* coef3, const float* w, float* dx, int B, int Cin,

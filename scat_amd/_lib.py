@@ -71,7 +71,8 @@ class _Lib:
             fn = getattr(self.cdll, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = rt
             fn.argtypes = [t for t, _ in at]
-            if rt is ctypes.c_int and name not in ("scat_version", "scat_get_math_mode", "scat_epilogue_stats_groups", "scat_splitk_reduce_pending"):
+            if rt is ctypes.c_int and name not in ("scat_version", "scat_get_math_mode", "scat_epilogue_stats_groups", "scat_splitk_reduce_pending",
+                                                      "scat_epilogue_bnb_groups"):
                 setattr(self, name, self._checked(fn, name))
             else:
                 setattr(self, name, fn)

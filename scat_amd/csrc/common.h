@@ -26,6 +26,10 @@ void append_kernel_label(const char* suffix);
 // records the group count for scat_epilogue_stats_groups) when one is armed and large enough, else nullptr.
 // *shift (optional out): the per-row reference the sums are taken about (scat_epilogue_stats_arm_shift), or nullptr
 float* epi_stats_take(int rows, int groups, const float** shift = nullptr);
+// BatchNorm-backward epilogue armed by the caller for the next qualifying accumulate launch of this host thread
+// (scat_epilogue_bnb_arm): true when armed and the buffers fit (rows x groups partial pairs, a tensor of n floats)
+struct EpiBnb { const float* x; const uint8_t* mask; const float* mean; float* part; int64_t cap; int64_t n; int groups; };
+bool epi_bnb_take(int rows, int groups, int64_t n, EpiBnb* out);
 
 // Every entry point returns through these: no exception crosses the C boundary.
 #define SCAT_REQUIRE(cond, code, ...)          \

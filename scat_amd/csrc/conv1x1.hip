@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NT, (BM * BN >= 128 * 128 ? 2 : 3)) void conv1x1_ke
 // pw_split_tile: the contraction stages [s_begin, s_end) of one output tile (a whole tile for the one-tile-per-workgroup
 // kernel; a K-segment of it for the persistent stream-K kernel below).  `post(acc)` runs on the finished accumulators
 // and says whether the epilogue (store_tile) follows.
-template <int WM, int BN, bool TF, bool DS, bool STEM, bool PL, class Post>
+template <int WM, int BN, bool TF, bool DS, bool STEM, bool PL, class Post, bool BNB = false>
 __device__ __forceinline__ void pw_split_tile(const PwDesc& d, const OutDesc& dc, const int tile, const int s_begin,
                                               const int s_end, Post post) {
     static_assert(!(TF && DS), "one input transform at a time");
@@ -503,7 +503,7 @@ __device__ __forceinline__ void pw_split_tile(const PwDesc& d, const OutDesc& dc
     }
     if (stamp) ts2 = __builtin_amdgcn_s_memrealtime();
     if (!post(acc)) return;
-    store_tile<1, NI, BM, BN, WM, WN>(acc, dc, d.M, d.npix, i0, j0, 0);
+    store_tile<1, NI, BM, BN, WM, WN, BNB>(acc, dc, d.M, d.npix, i0, j0, 0);
     if (stamp) {
         __syncthreads();
         if (tid == 0 && dc.mode == 1) {
@@ -519,7 +519,7 @@ __device__ __forceinline__ void pw_split_tile(const PwDesc& d, const OutDesc& dc
 }
 
 // one tile per workgroup, XCD-aware tile order
-template <int WM, int BN, bool TF, bool DS = false, bool STEM = false, bool PL = false>
+template <int WM, int BN, bool TF, bool DS = false, bool STEM = false, bool PL = false, bool BNB = false>
 __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc dc) {
     constexpr int BM = 32 * WM;
     const int mt = (d.M + BM - 1) / BM, nt = (d.npix + BN - 1) / BN;
@@ -535,7 +535,8 @@ __global__ __launch_bounds__(NT, 3) void conv1x1_split_kernel(PwDesc d, OutDesc 
             while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
         }
     }
-    pw_split_tile<WM, BN, TF, DS, STEM, PL>(d, dc, tile, 0, nstage, [](auto&) { return true; });
+    auto all = [](auto&) { return true; };
+    pw_split_tile<WM, BN, TF, DS, STEM, PL, decltype(all), BNB>(d, dc, tile, 0, nstage, all);
 }
 
 // ---------------------------------------------------------------- persistent stream-K schedule
@@ -1246,6 +1247,20 @@ static void launch_pw_split(const PwDesc& d, const OutDesc& dc_in, hipStream_t s
         dc.stats = epi_stats_take(d.M, dc.sg, &dc.stats_shift);
     }
     if (!dc.accumulate) dc.st_aux = store_policy(dc.n * 4);
+    if constexpr (!STEM && !DS && !TF && WM == 4 && BN == 128) {
+        // a data gradient that completes the gradient of a block output (C += ...): the BatchNorm backward's reduction
+        // of the block that produced it rides in the epilogue when the caller armed it (scat_epilogue_bnb_arm)
+        EpiBnb eb;
+        if (dc.accumulate && !dc.bias && dc.mode == 1 && d.ntap == 1 && d.C % 32 == 0 && pw_plain_mode() &&
+            epi_bnb_take(d.M, nt * (4 / WM), dc.n, &eb)) {
+            dc.bnb_x = eb.x; dc.bnb_mask = eb.mask; dc.bnb_mean = eb.mean; dc.bnb_part = eb.part;
+            dc.bnb_sg = nt * (4 / WM);
+            hipLaunchKernelGGL((conv1x1_split_kernel<WM, BN, TF, DS, false, true, true>), dim3(mt * nt), dim3(NT), lds_bytes,
+                               st, d, dc);
+            append_kernel_label("_bnb");
+            return;
+        }
+    }
     if constexpr (!STEM && BN == 128) {
         // persistent stream-K grid when the caller armed a scratch buffer and the launch has enough tiles to share out
         SkDesc sk{};

@@ -76,6 +76,16 @@ struct OutDesc {
     int st_aux;                 // cache policy of the epilogue's stores (store_tile): 0 default, 16 sc1, 2 nt
     const float* stats_shift;   // optional per-row reference c[row]: the sums are of (x - c) and (x - c)^2 — fp32 partials of
                                 // x^2 cancel catastrophically in E[x^2] - mean^2 when |mean| >> sigma (scat_epilogue_stats_arm_shift)
+    // BatchNorm-backward epilogue (store_tile<..., BNB = true>, accumulate only; scat_epilogue_bnb_arm): the tensor being
+    // completed is the gradient of  relu(bn(x) + residual)  — mask it with the output's sign bits (bit e % 4 of byte
+    // e / 4), store the MASKED gradient g, and leave per row (= channel) and column group the sums of g and
+    // g * (x - bnb_mean[row]) in bnb_part[(row * bnb_sg + group) * 2 + {0, 1}]: the reduction pass of that BatchNorm's
+    // backward without reading the gradient back
+    const float* bnb_x;
+    const uint8_t* bnb_mask;
+    const float* bnb_mean;
+    float* bnb_part;
+    int bnb_sg;
 };
 
 // ---------------------------------------------------------------- loaders
@@ -398,7 +408,7 @@ __device__ __forceinline__ void static_for(F f) { static_for_impl<0, N>(f); }
 // Branch-free: 32-bit element offsets, raw buffer stores whose out-of-range lanes (tile edge) are
 // dropped by the hardware bounds check; the (accumulate, bias) variants are separate straight-line
 // copies selected once by uniform branches.
-template <int MI, int NI, int BM, int BN, int WM, int WN>
+template <int MI, int NI, int BM, int BN, int WM, int WN, bool BNB = false>
 __device__ __forceinline__ void store_tile(f32x16 (&acc)[MI][NI], const OutDesc& dc, int M, int N, int i0, int j0,
                                            int z) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -428,6 +438,90 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[MI][NI], const OutDesc&
         bj[b] = (dc.bias && dc.bias_mode == 2) ? dc.bias[jc] : 0.f;
     }
     const int ibase = i0 + wm * (BM / WM) + 4 * lh;
+    if constexpr (BNB) {
+        // BatchNorm-backward epilogue (OutDesc::bnb_*): C = mask(C_old + acc), row sums of g and g * (x - mean) per column
+        // group.  Two rows at a time (registers: the caller's 64 accumulators stay live), a row quad's sums are reduced
+        // over the 32 lanes of the row and written before the next quad.
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(dc.bnb_x, dc.n);
+        const __amdgpu_buffer_rsrc_t rm =
+            __builtin_amdgcn_make_buffer_rsrc((void*)dc.bnb_mask, 0, (int)((dc.n + 3) / 4), 0x00020000);
+        const int grp = (j0 / BN) * WN + wn;
+#pragma unroll
+        for (int a = 0; a < MI; ++a) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+                static_for<2>([&](auto h_tag) {
+                    constexpr int H2 = 2 * decltype(h_tag)::value;
+                    int voff[2][NI];
+                    float val[2][NI], old[2][NI], xv[2][NI], mu[2];
+                    uint32_t mb[2][NI];
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        const int i = ibase + a * 32 + H2 + r2 + 8 * rq;
+                        const bool rowok = i < M;
+                        mu[r2] = dc.bnb_mean[rowok ? i : 0];
+#pragma unroll
+                        for (int b = 0; b < NI; ++b) {
+                            voff[r2][b] = (rowok && colok[b]) ? (coloff[b] + i * rstride) * 4 : OOB;
+                            val[r2][b] = acc[a][b][rq * 4 + H2 + r2];
+                        }
+                    }
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b) {
+                            old[r2][b] = bload(rc, voff[r2][b]);
+                            xv[r2][b] = bload(rx, voff[r2][b]);
+                            mb[r2][b] = __builtin_amdgcn_raw_buffer_load_b8(rm, voff[r2][b] == OOB ? OOB : (voff[r2][b] >> 4), 0, 0);
+                        }
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b) {
+                            const bool live = voff[r2][b] != OOB && ((mb[r2][b] >> ((voff[r2][b] >> 2) & 3)) & 1u);
+                            const float g = live ? val[r2][b] + old[r2][b] : 0.f;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g), rc, voff[r2][b], 0, 0);
+                            s4[H2 + r2] += g;
+                            q4[H2 + r2] = fmaf(g, xv[r2][b] - mu[r2], q4[H2 + r2]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                // reduce-scatter over the 32 lanes of a row: lane bit 4 keeps rows {2, 3} or {0, 1}, bit 3 the odd or the even
+                // one, then a butterfly over the eight lanes that hold the same row
+                {
+                    const bool up = (lane & 16) != 0;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float ks = up ? s4[k + 2] : s4[k], xs = up ? s4[k] : s4[k + 2];
+                        const float kq = up ? q4[k + 2] : q4[k], xq = up ? q4[k] : q4[k + 2];
+                        s4[k] = ks + __shfl_xor(xs, 16);
+                        q4[k] = kq + __shfl_xor(xq, 16);
+                    }
+                }
+                {
+                    const bool up = (lane & 8) != 0;
+                    const float ks = up ? s4[1] : s4[0], xs = up ? s4[0] : s4[1];
+                    const float kq = up ? q4[1] : q4[0], xq = up ? q4[0] : q4[1];
+                    s4[0] = ks + __shfl_xor(xs, 8);
+                    q4[0] = kq + __shfl_xor(xq, 8);
+                }
+#pragma unroll
+                for (int bit = 4; bit >= 1; bit >>= 1) {
+                    s4[0] += __shfl_xor(s4[0], bit);
+                    q4[0] += __shfl_xor(q4[0], bit);
+                }
+                const int rr = ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+                const int i = ibase + a * 32 + rr + 8 * rq;
+                if ((lane & 7) == 0 && i < M) {
+                    float* o = dc.bnb_part + ((int64_t)i * dc.bnb_sg + grp) * 2;
+                    o[0] = s4[0];
+                    o[1] = q4[0];
+                }
+            }
+        }
+        return;
+    }
     auto emit = [&](auto acc_tag, auto bias_tag) {
         constexpr bool ACC = decltype(acc_tag)::value;
         constexpr bool BIASI = decltype(bias_tag)::value;

@@ -44,6 +44,17 @@ float* epi_stats_take(int rows, int groups, const float** shift) {
     return b;
 }
 
+static thread_local EpiBnb g_bnb = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+bool epi_bnb_take(int rows, int groups, int64_t n, EpiBnb* out) {
+    const EpiBnb b = g_bnb;
+    g_bnb.part = nullptr;
+    g_bnb.groups = 0;
+    if (!b.part || !b.x || !b.mask || !b.mean || b.n != n || (int64_t)rows * groups * 2 > b.cap) return false;
+    g_bnb.groups = groups;
+    *out = b;
+    return true;
+}
+
 static int g_math_mode = -1;
 int math_mode() {
     if (g_math_mode < 0) {
@@ -797,6 +808,17 @@ extern "C" int scat_epilogue_stats_arm_shift(float* buf, int64_t bytes, const fl
     scat_epilogue_stats_arm(buf, bytes);
     scat::g_epi.shift = buf ? shift : nullptr;
     return SCAT_OK;
+}
+extern "C" int scat_epilogue_bnb_arm(const float* x, const uint8_t* mask, const float* mean, int64_t n, float* part,
+                                     int64_t part_bytes) {
+    scat::g_bnb = scat::EpiBnb{x, mask, mean, (x && mask && mean) ? part : nullptr, part ? part_bytes / 4 : 0, n, 0};
+    return SCAT_OK;
+}
+extern "C" int scat_epilogue_bnb_groups(void) {
+    const int g = scat::g_bnb.groups;
+    scat::g_bnb.part = nullptr;
+    scat::g_bnb.groups = 0;
+    return g;
 }
 extern "C" int scat_epilogue_stats_groups(void) {
     const int g = scat::g_epi.groups;

@@ -764,6 +764,36 @@ __global__ void bn_bwd_finalize3_kernel(const double* __restrict__ part, int C, 
     coef3[2 * C + c] = -ca * k1 - cb * mean[c];
 }
 
+// The same finish from the sums a data-gradient kernel's epilogue left behind (OutDesc::bnb_part, gemm_engine.h store_tile):
+// part[c][G][2] = (sum of g, sum of g * (x - mean[c])) of channel c over column group g, fp32; summed here in fp64, fixed order.
+__global__ __launch_bounds__(256) void bn_bwd_partials_fin3_kernel(const float* __restrict__ part, int G, int C, double count,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                   float* __restrict__ coef3) {
+    const int c = blockIdx.x;
+    const float2* p = (const float2*)part + (int64_t)c * G;
+    double s1 = 0, s2 = 0;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        const float2 v = p[g];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+    __shared__ double sh[8];
+    block_sum2(s1, s2, sh);
+    if (threadIdx.x == 0) {
+        s2 *= (double)invstd[c];                       // sum of g * xhat
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+        const float k1 = (float)(s1 / count), k2 = (float)(s2 / count);
+        const float ca = gamma[c] * invstd[c], cb = -ca * invstd[c] * k2;
+        coef3[c] = ca;
+        coef3[C + c] = cb;
+        coef3[2 * C + c] = -ca * k1 - cb * mean[c];
+    }
+}
+
 // dx may alias dy, dres may alias dy: every element is read before it is written by the same thread
 template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, const float* __restrict__ x,
@@ -1174,6 +1204,20 @@ extern "C" int scat_bn_bwd_pre(float* dy_g, const float* dy_add, const float* x,
         hipLaunchKernelGGL(bn_bwd_finalize3_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)part, C, S,
                            (double)B * HW, gamma, save_mean, save_invstd, dgamma, dbeta, coef3);
     SCAT_LAUNCH_CHECK("scat_bn_bwd_pre");
+    return SCAT_OK;
+}
+
+// coef3 / dgamma / dbeta of scat_bn_bwd_pre from the partial sums a data-gradient epilogue wrote (scat_epilogue_bnb_arm):
+// the masked gradient is already in place, this is only the finish
+extern "C" int scat_bn_bwd_pre_partials(const float* partials, int groups, int B, int C, int HW, const float* save_mean,
+                                        const float* save_invstd, const float* gamma, float* dgamma, float* dbeta,
+                                        float* coef3, void* stream) {
+    SCAT_REQUIRE(partials && save_mean && save_invstd && gamma && dgamma && dbeta && coef3, SCAT_E_ARG,
+                 "scat_bn_bwd_pre_partials: null pointer");
+    SCAT_REQUIRE(groups > 0 && B > 0 && C > 0 && HW > 0, SCAT_E_SHAPE, "scat_bn_bwd_pre_partials: non-positive dimension");
+    hipLaunchKernelGGL(bn_bwd_partials_fin3_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, groups, C,
+                       (double)B * HW, gamma, save_mean, save_invstd, dgamma, dbeta, coef3);
+    SCAT_LAUNCH_CHECK("scat_bn_bwd_pre_partials");
     return SCAT_OK;
 }
 

@@ -92,6 +92,7 @@ SIDE_SHORTCUT = _sw.ab("SCAT_SIDE_SHORTCUT", True)   # forward: the shortcut con
 SIDE_DS_BN = _sw.ab("SCAT_SIDE_DS_BN", True)   # the shortcut's BatchNorm backward beside the main data-gradient chain
 STEM_FUSED_BWD = _sw.ab("SCAT_STEM_FUSED_BWD", True)   # max-pool backward inside bn1's backward (stem)
 SIDE_WGRAD = _sw.ab("SCAT_SIDE_WGRAD", True)   # bench.py clears it for its serialized, per-kernel-timed step
+EPI_BNB = _sw.ab("SCAT_EPI_BNB", True)   # bn3's backward reduction in the epilogue of the kernel that completes its gradient
 
 
 def _side_stream(device, who="backbone"):
@@ -239,14 +240,25 @@ class _Bwd:
             ops.wgrad_defer(False)
 
 
-def _block_backward(bc, rec, dcur):
+def _fold3(bc, rec):
+    """is bn3's backward of this block split (reduce here, apply inside conv3's gradient kernels)?"""
+    blk, c3, omask = rec[0], rec[6], rec[11]
+    return (bc.use_bnb and omask is not None and blk.conv3.weight.shape[0] % 16 == 0 and c3.shape[2] >= BNB_MIN_H)
+
+
+def _block_backward(bc, rec, dcur, nxt=None, pre3=None):
     """Backward of one Bottleneck from its tape record: dcur = gradient of the block output (modified in place: the
-    masked gradient is also the residual branch's gradient) -> gradient of the block input."""
+    masked gradient is also the residual branch's gradient) -> (gradient of the block input, pre3 for the next call).
+
+    nxt: the record of the block whose OUTPUT this block's input is (the next call's ``rec``), or None.  When this block's
+    shortcut is the identity, its last kernel — conv1's data gradient, accumulated onto the masked gradient — completes the
+    gradient of that block's output: armed (EPI_BNB), its epilogue applies that block's output mask and leaves the sums
+    of its bn3 backward, and the next call receives them as ``pre3`` = (partials, groups) instead of running the
+    reduction pass over the three tensors again."""
     blk, xin, c1, s1, c2, s2, c3, s3, cd, sd, out, omask = rec
     gbuf, put, wgrad, wgrad_bnb, wp, pending = bc.gbuf, bc.put, bc.wgrad, bc.wgrad_bnb, bc.wp, bc.pending
     # out = relu(bn3(c3) + res): g = dcur * (out>0) is also the residual branch's gradient
-    fold3 = (bc.use_bnb and omask is not None and blk.conv3.weight.shape[0] % 16 == 0
-             and c3.shape[2] >= BNB_MIN_H)
+    fold3 = _fold3(bc, rec)
     if pending[0] is not None and not fold3:
         dcur = ops.axpy(dcur, pending[0], 1.0, out=dcur)
         pending[0] = None
@@ -254,9 +266,13 @@ def _block_backward(bc, rec, dcur):
     ev3 = None
     w3 = blk.conv3.weight
     if fold3:
-        coef3, dg, db = ops.bn_bwd_pre(dcur, c3, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
-                                       gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), y_mask=omask,
-                                       dy_add=pending[0])
+        if pre3 is not None:       # dcur IS the masked gradient already, its sums came with it
+            coef3, dg, db = ops.bn_bwd_pre_partials(pre3[0], pre3[1], tuple(c3.shape), s3.mean, s3.invstd, blk.bn3.weight,
+                                                    gbuf(blk.bn3.weight), gbuf(blk.bn3.bias))
+        else:
+            coef3, dg, db = ops.bn_bwd_pre(dcur, c3, True, s3.scale, s3.shift, s3.mean, s3.invstd, blk.bn3.weight,
+                                           gbuf(blk.bn3.weight), gbuf(blk.bn3.bias), y_mask=omask,
+                                           dy_add=pending[0])
         pending[0] = None
         put(blk.bn3.weight, dg), put(blk.bn3.bias, db)
         dw3, ev3 = wgrad_bnb(g, c3, coef3, c2, w3, s2.scale, s2.shift, True)   # g is overwritten further down
@@ -327,14 +343,24 @@ def _block_backward(bc, rec, dcur):
                         # of the whole plane)
     else:
         dxin = g
+    pre_next = None
     if fold1:
         dcur = ops.conv1x1_dgrad_bnb(da1, c1, coef1, w1, tuple(xin.shape), out=dxin, accumulate=dxin is not None,
                                      wp=wp)
     else:
-        dcur = ops.conv2d_dgrad_w(dc1, w1, tuple(xin.shape), 1, 0, out=dxin, accumulate=dxin is not None, wp=wp)
+        arm = (EPI_BNB and nxt is not None and dxin is not None and pending[0] is None and _fold3(bc, nxt)
+               and nxt[10].data_ptr() == xin.data_ptr())
+        if arm:
+            part = ops.epilogue_bnb_arm(nxt[6], nxt[11], nxt[7].mean)
+        try:
+            dcur = ops.conv2d_dgrad_w(dc1, w1, tuple(xin.shape), 1, 0, out=dxin, accumulate=dxin is not None, wp=wp)
+        finally:
+            groups = ops.epilogue_bnb_groups() if arm else 0
+        if groups:
+            pre_next = (part, groups)
     if cd is not None:
         dcur = ops.conv2d_dgrad_w(dcd, dsw, tuple(xin.shape), blk.stride, 0, out=dcur, accumulate=True, wp=wp)
-    return dcur
+    return dcur, pre_next
 
 
 class _BlockFn(torch.autograd.Function):
@@ -367,7 +393,7 @@ class _BlockFn(torch.autograd.Function):
             raise RuntimeError("scat_amd: Bottleneck backward needs a training-mode forward (BN batch statistics)")
         bc = _Bwd(None, dout.device, getattr(ctx.rec[0], "_wprep", None))
         dcur = dout.contiguous().clone()               # masked in place below; the caller's tensor stays intact
-        dx = _block_backward(bc, ctx.rec, dcur)
+        dx, _ = _block_backward(bc, ctx.rec, dcur)
         bc.join()
         params, ctx.rec = ctx.params, None
         return (dx if ctx.needs_input_grad[0] else None, None, *[bc.grads.get(p) for p in params])
@@ -515,8 +541,11 @@ class _BackboneFn(torch.autograd.Function):
         li = lids[-1]
         remaining = len(layers[li])
         dcur = add_ext(dcur, stage_grads[li], x4)
-        for rec in reversed(tape):
-            dcur = _block_backward(bc, rec, dcur)
+        recs = list(reversed(tape))
+        pre3 = None
+        for k, rec in enumerate(recs):
+            nxt = recs[k + 1] if remaining > 1 and k + 1 < len(recs) else None     # (the next block of the SAME stage)
+            dcur, pre3 = _block_backward(bc, rec, dcur, nxt, pre3)
             remaining -= 1
             if remaining == 0:
                 if sink is not None:

@@ -777,6 +777,34 @@ def bn_bwd_pre(dy, x, relu, scale, shift, save_mean, save_invstd, gamma, dgamma=
     return coef3, dgamma, dbeta
 
 
+def epilogue_bnb_arm(x, mask, mean):
+    """Arm the next accumulating pointwise data gradient on this host thread (include/scat_hip.h scat_epilogue_bnb_arm): it
+    completes the gradient of relu(bn(x) + residual); its epilogue masks it with ``mask`` and leaves the BatchNorm
+    backward's two sums per channel.  -> the partials' workspace (pass it to bn_bwd_pre_partials with epilogue_bnb_groups())."""
+    _chk(x, mean)
+    B, C, H, W = x.shape
+    nbytes = C * ((B * H * W + 31) // 32 + 4) * 8
+    part = workspace(nbytes, x.device, "bnbpart")
+    lib().scat_epilogue_bnb_arm(_p(x), _p(mask), _p(mean), x.numel(), _p(part), nbytes)
+    return part
+
+
+def epilogue_bnb_groups():
+    return lib().scat_epilogue_bnb_groups()
+
+
+def bn_bwd_pre_partials(part, groups, x_shape, save_mean, save_invstd, gamma, dgamma=None, dbeta=None):
+    """(coef3, dgamma, dbeta) of bn_bwd_pre from the sums an armed data-gradient epilogue left (the masked gradient is in place)"""
+    _chk(save_mean, save_invstd, gamma, dgamma, dbeta)
+    B, C, H, W = x_shape
+    dgamma = dgamma if dgamma is not None else torch.empty_like(gamma)
+    dbeta = dbeta if dbeta is not None else torch.empty_like(gamma)
+    coef3 = torch.empty((3, C), dtype=torch.float32, device=gamma.device)
+    lib().scat_bn_bwd_pre_partials(_p(part), groups, B, C, H * W, _p(save_mean), _p(save_invstd), _p(gamma), _p(dgamma),
+                                   _p(dbeta), _p(coef3), _stream())
+    return coef3, dgamma, dbeta
+
+
 def conv1x1_dgrad_bnb(g, z, coef3, w, x_shape, out=None, accumulate=False, wp=None):
     _chk(g, z, coef3, w, out)
     B, Cin, H, W = x_shape

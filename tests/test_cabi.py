@@ -32,6 +32,7 @@ def test_header_declares_the_path():
                                                 "scat_set_math_mode",
                                                 # host-side state of the NEXT launch of this thread, no device work
                                                 "scat_epilogue_stats_arm", "scat_epilogue_stats_arm_shift", "scat_epilogue_stats_groups",
+                                                "scat_epilogue_bnb_arm", "scat_epilogue_bnb_groups",
                                                 "scat_streamk_arm",
                                                 # host-side record of reduces to be flushed later (the flush takes the stream)
                                                 "scat_splitk_defer", "scat_splitk_reduce_pending", "scat_splitk_reduce_discard"):

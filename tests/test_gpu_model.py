@@ -688,7 +688,7 @@ def test_bottleneck_batch96_against_fp64(key, cin, H, stride):
     m2 = (c2.double() * s2.scale.double().view(1, -1, 1, 1) + s2.shift.double().view(1, -1, 1, 1) > 0).cpu()
     m3 = (out > 0).cpu()
     bc = R._Bwd(None, out.device, None)
-    dx = R._block_backward(bc, rec, cot.cuda().clone())
+    dx, _ = R._block_backward(bc, rec, cot.cuda().clone())
     bc.join()
     torch.cuda.synchronize()
     got = {"dx": dx}

@@ -1476,3 +1476,38 @@ def _deferred_splitk_reduces(ops, lib):
     ops.wgrad_flush()
     torch.cuda.synchronize()
     assert sum(bool(torch.isnan(o).all()) for o in stale) == npend
+
+
+@pytest.mark.parametrize("B,C,K,H", [(5, 256, 64, 28), (3, 512, 128, 28), (2, 256, 64, 56)])
+def test_bn_backward_sums_in_the_data_gradient_epilogue(ops, B, C, K, H):
+    """The gradient of a Bottleneck output is completed by the next block's conv1 data gradient, accumulated onto the
+    shortcut's gradient (models/resnet.py:93-96).  Armed (scat_epilogue_bnb_arm), that kernel's epilogue applies the
+    output's sign mask and leaves bn3's backward sums: the masked gradient must be bit for bit what the accumulate followed
+    by scat_bn_bwd_pre writes, coef3 / d-gamma / d-beta the same to rounding (fp32 tile sums, then fp64)."""
+    c3 = g(t(701, "c3", (B, C, H, H)) * 1.3 + 0.2)
+    res = g(t(702, "res", (B, C, H, H)))
+    gamma = g(torch.from_numpy(synth.uniform(703, "g", (C,), 0.5, 1.5)))
+    beta = g(torch.from_numpy(synth.uniform(704, "b", (C,), -0.3, 0.3)))
+    rm, rv = g(torch.zeros(C)), g(torch.ones(C))
+    mean, invstd, scale, shift = ops.bn_train_stats(c3, gamma, beta, rm, rv)
+    out, mask = ops.bn_apply(c3, scale, shift, res, True, want_mask=True)
+    assert mask is not None
+    dc1 = g(t(705, "dc1", (B, K, H, H)))
+    w1 = g(t(706, "w1", (K, C, 1, 1)) * 0.1)
+    g_old = g(t(707, "gold", (B, C, H, H)))
+    # reference: accumulate, then the reduction pass
+    ref = ops.conv2d_dgrad_w(dc1, w1, (B, C, H, H), 1, 0, out=g_old.clone(), accumulate=True)
+    coef_r, dg_r, db_r = ops.bn_bwd_pre(ref, c3, True, scale, shift, mean, invstd, gamma, y_mask=mask)
+    # armed epilogue
+    part = ops.epilogue_bnb_arm(c3, mask, mean)
+    new = ops.conv2d_dgrad_w(dc1, w1, (B, C, H, H), 1, 0, out=g_old.clone(), accumulate=True)
+    groups = ops.epilogue_bnb_groups()
+    assert groups > 0 and ops.lib().scat_last_kernel().decode().endswith("_bnb"), ops.lib().scat_last_kernel()
+    coef_n, dg_n, db_n = ops.bn_bwd_pre_partials(part, groups, (B, C, H, H), mean, invstd, gamma)
+    assert torch.equal(new, ref)
+    assert rel_err(dg_n, dg_r) < 1e-5 and rel_err(db_n, db_r) < 1e-5
+    for k in range(3):
+        assert rel_err(coef_n[k], coef_r[k]) < 1e-5
+    # the arm is one-shot: the next call is the plain accumulate again
+    again = ops.conv2d_dgrad_w(dc1, w1, (B, C, H, H), 1, 0, out=g_old.clone(), accumulate=True)
+    assert ops.epilogue_bnb_groups() == 0 and not torch.equal(again, ref)

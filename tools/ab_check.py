@@ -10,7 +10,7 @@ import sys
 OFF = dict(SCAT_DIAG="1", SCAT_OVERLAP_TOKENS="0", SCAT_SIDE_WGRAD="0", SCAT_EARLY_ADAM="0", SCAT_WPREP="0", SCAT_BNB="0",
            SCAT_SUBSAMPLE="0", SCAT_DX2_FOLD="0", SCAT_SIDE_HEAD="0", SCAT_EPI_STATS="0", SCAT_SIDE_SHORTCUT="0",
            SCAT_SIDE_DS_BN="0", SCAT_STEM_FUSED_BWD="0", SCAT_STAT_REF="0", SCAT_GROUP_WGRAD="0", SCAT_TOKENS_FIRST="0",
-           SCAT_STREAMS_PROBE="0", SCAT_BN_ONEPASS="0", SCAT_BN_LASTBLOCK="0")
+           SCAT_STREAMS_PROBE="0", SCAT_BN_ONEPASS="0", SCAT_BN_LASTBLOCK="0", SCAT_EPI_BNB="0")
 CHILD = r'''
 import sys, random, torch
 sys.path.insert(0, ".")
