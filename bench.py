@@ -209,6 +209,7 @@ def instantiation_of(label, traffic=None):
     import re
     tf = "t" if label.endswith("_tf") or "_tf_" in label else "f"
     ds = "t" if "_bnb" in label else "f"      # dual-source operand (folded BatchNorm backward)
+    epi = "t" if label.endswith("_epibn") else "f"      # BatchNorm-backward sums in the epilogue (scat_epilogue_bnb_arm)
     m = re.search(r"_split_pc(\d+)x128x32", label)
     if m:
         return f"conv1x1_pc_kernel<{int(m.group(1)) // 128},{tf},0>"
@@ -217,7 +218,7 @@ def instantiation_of(label, traffic=None):
         stem = "t" if label.startswith("conv7x7_s2_split") else "f"
         base = f"conv1x1_split_kernel<{int(m.group(1)) // 32},{m.group(2)},{tf},{ds},{stem}"
         # one tap and C % 32 == 0 (every pointwise layer of the networks) launch the mask-free staging variant
-        cands = ([f"{base},t>"] if stem == "f" else []) + [f"{base},f>"]
+        cands = ([f"{base},t,{epi}>"] if stem == "f" else []) + [f"{base},f,{epi}>"]
         for c in cands:
             if traffic is not None and c in traffic:
                 return c

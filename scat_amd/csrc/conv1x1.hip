@@ -1257,7 +1257,7 @@ static void launch_pw_split(const PwDesc& d, const OutDesc& dc_in, hipStream_t s
             dc.bnb_sg = nt * (4 / WM);
             hipLaunchKernelGGL((conv1x1_split_kernel<WM, BN, TF, DS, false, true, true>), dim3(mt * nt), dim3(NT), lds_bytes,
                                st, d, dc);
-            append_kernel_label("_bnb");
+            append_kernel_label("_epibn");
             return;
         }
     }

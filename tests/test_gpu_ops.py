@@ -1502,7 +1502,7 @@ def test_bn_backward_sums_in_the_data_gradient_epilogue(ops, B, C, K, H):
     part = ops.epilogue_bnb_arm(c3, mask, mean)
     new = ops.conv2d_dgrad_w(dc1, w1, (B, C, H, H), 1, 0, out=g_old.clone(), accumulate=True)
     groups = ops.epilogue_bnb_groups()
-    assert groups > 0 and ops.lib().scat_last_kernel().decode().endswith("_bnb"), ops.lib().scat_last_kernel()
+    assert groups > 0 and ops.lib().scat_last_kernel().decode().endswith("_epibn"), ops.lib().scat_last_kernel()
     coef_n, dg_n, db_n = ops.bn_bwd_pre_partials(part, groups, (B, C, H, H), mean, invstd, gamma)
     assert torch.equal(new, ref)
     assert rel_err(dg_n, dg_r) < 1e-5 and rel_err(db_n, db_r) < 1e-5
