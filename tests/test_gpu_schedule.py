@@ -54,36 +54,50 @@ def test_step_streams_do_not_share_hardware_queues():
     assert any(any(streams._shares(s, h) for h in heavy) for s in more)
 
 
+_CAPTURE_CHILD = r"""
+import random, sys
+import torch
+sys.path.insert(0, ".")
+import bench
+from scat_amd import graphed
+
+config, batch = sys.argv[1], int(sys.argv[2])
+dev = torch.device("cuda", 0)
+
+
+def run(graph):
+    random.seed(7)
+    net = bench.make_net(config, 1, dev)
+    net.mask_rate = 0.0
+    step = bench.Step(config, net, dev)
+    u8, lab = bench.build_inputs(batch, 100, dev)
+    gs = graphed.GraphedStep(lambda: step(u8, lab), warmup=3 if graph else 1 << 30)
+    for _ in range(4):
+        out = gs()
+    torch.cuda.synchronize()
+    assert (gs.graph is not None) == graph
+    return [p.detach().clone() for p in net.parameters()], out[0].detach().clone()
+
+
+p_eager, l_eager = run(False)
+p_graph, l_graph = run(True)
+assert torch.isfinite(l_eager).all() and torch.equal(l_eager, l_graph), (l_eager, l_graph)
+assert all(torch.equal(a, b) for a, b in zip(p_eager, p_graph))
+print("CAPTURE-OK")
+"""
+
+
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("config,batch", [("resnet50", 8), ("hrnet_w32", 4)])
 def test_whole_step_is_stream_capturable(config, batch):
     """A whole train step — forward, backward on every side stream, update — can be captured into ONE HIP graph, and the
     replay leaves exactly the bits the eager step leaves (scat_amd/graphed.py: the fork / join graph of the step is a star
     around the calling stream; branch streams never wait on each other, no work on the legacy default stream).  The
-    masked-token draw is off: its upload is host work a capture cannot hold."""
-    import random
+    masked-token draw is off: its upload is host work a capture cannot hold.  In a child process: what this guards
+    against showed up as segmentation faults inside hipStreamEndCapture, which must not take the test run down."""
+    import subprocess
 
-    import torch
-
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-    import bench
-    from scat_amd import graphed
-
-    dev = torch.device("cuda", 0)
-
-    def run(graph):
-        random.seed(7)
-        net = bench.make_net(config, 1, dev)
-        net.mask_rate = 0.0
-        step = bench.Step(config, net, dev)
-        u8, lab = bench.build_inputs(batch, 100, dev)
-        gs = graphed.GraphedStep(lambda: step(u8, lab), warmup=3 if graph else 1 << 30)
-        for _ in range(4):
-            out = gs()
-        torch.cuda.synchronize()
-        assert (gs.graph is not None) == graph
-        return [p.detach().clone() for p in net.parameters()], out[0].detach().clone()
-
-    p_eager, l_eager = run(False)
-    p_graph, l_graph = run(True)
-    assert torch.isfinite(l_eager).all() and torch.equal(l_eager, l_graph)
-    assert all(torch.equal(a, b) for a, b in zip(p_eager, p_graph))
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    r = subprocess.run([sys.executable, "-c", _CAPTURE_CHILD, config, str(batch)], cwd=root, capture_output=True, text=True,
+                       timeout=550)
+    assert r.returncode == 0 and "CAPTURE-OK" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-1200:])
