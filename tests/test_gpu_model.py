@@ -1055,3 +1055,97 @@ def test_literal_train_py_sequence_through_dropin(golden):
         assert digest_err(digest(net.regressor.weight, 32), g[f"s{step}:regressor.weight"]) < (2e-3 if step == 1 else 5e-3)
         assert digest_err(digest(net.main_encoder.conv1.weight, 32), g[f"s{step}:conv1.weight"]) < (1e-4 if step == 1 else 5e-2)
     assert int(net.main_encoder.bn1.num_batches_tracked) == int(g["nbt"]) == 2
+
+
+@pytest.mark.timeout(1200)
+def test_backbone_gradients_against_fp64_with_the_runs_own_patterns():
+    """The WHOLE fused ResNet-50 backbone (models/resnet.py:100-160: stem, max-pool, sixteen Bottlenecks, average pool, fc1),
+    forward and backward through the real autograd node, held tight the way the single blocks are
+    (test_bottleneck_batch96_against_fp64): the piecewise-linear pieces of the network — 49 ReLUs and the max-pool's
+    arg-max — are taken from the HIP run (sign of fma(c, scale, shift) as the kernels form it, the sign of every block
+    output, the pool's tap indices) and the oracle's layers are evaluated in fp64 WITH those patterns.  What is left is
+    smooth, so every one of the 161 parameter gradients has to agree to rounding — against the goldens of the real
+    reference the same gradients can only be held to 0.25, because one flipped ReLU of millions moves them by that much."""
+    import torch.nn.functional as F
+    from scat_amd import ops as OPS
+    from scat_amd.models import resnet as R
+
+    B = 12
+    net = R.resnet50(pretrained=False, num_classes=512)
+    full = synth.to_torch(synth.resnet_state(61, ""))
+    net.load_state_dict(full, strict=True)
+    net = net.cuda().train()
+    x = T(synth.images(62, B))
+    cot_f = T(synth.normal_like(63, "cot_feat", (B, 1024)))
+    cot_2 = T(synth.normal_like(64, "cot_x2", (B, 512, 28, 28))) * 0.05
+
+    recs, stem = [], {}
+    bf, mp = R._block_forward, OPS.maxpool_fwd
+
+    def bf_rec(*a, **k):
+        rec = bf(*a, **k)
+        recs.append(rec)
+        return rec
+
+    def mp_rec(c0, scale=None, shift=None, relu=False):
+        y, idx = mp(c0, scale, shift, relu)
+        stem.update(c0=c0, scale=scale, shift=shift, idx=idx)
+        return y, idx
+
+    R._block_forward, OPS.maxpool_fwd = bf_rec, mp_rec
+    try:
+        feat, x1, x2, x3, x4 = net(x.cuda())
+        ((feat * cot_f.cuda()).sum() + (x2 * cot_2.cuda()).sum()).backward()
+    finally:
+        R._block_forward, OPS.maxpool_fwd = bf, mp
+    torch.cuda.synchronize()
+    assert len(recs) == 16 and stem
+    got = {k: p.grad.detach().cpu().double() for k, p in net.named_parameters()}
+
+    def fma_sign(c, s):
+        return (c.double() * s.scale.double().view(1, -1, 1, 1) + s.shift.double().view(1, -1, 1, 1) > 0).cpu()
+
+    # ---- the run's patterns
+    m0 = (stem["c0"].double() * stem["scale"].double().view(1, -1, 1, 1) + stem["shift"].double().view(1, -1, 1, 1) > 0).cpu()
+    idx = stem["idx"].cpu().long()                                   # tap kh * 3 + kw of the window's maximum
+    OH, OW = idx.shape[2:]
+    oy = torch.arange(OH).view(1, 1, OH, 1)
+    ox = torch.arange(OW).view(1, 1, 1, OW)
+    flat = ((2 * oy - 1 + idx // 3) * (2 * OW) + (2 * ox - 1 + idx % 3)).reshape(B, 64, -1)       # into the 112 x 112 plane
+    masks = [(fma_sign(r[2], r[3]), fma_sign(r[4], r[5]), (r[10] > 0).cpu()) for r in recs]
+    mpool = (x4.double().mean((2, 3)) > 0).cpu()
+    mfeat = (feat > 0).cpu()
+
+    # ---- the oracle's layers in fp64 with those patterns
+    sd = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in full.items()}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    xd = x.double()
+    a0 = O.batch_norm(sd, "bn1", F.conv2d(xd, sd["conv1.weight"], stride=2, padding=3), True) * m0
+    cur = a0.reshape(B, 64, -1).gather(2, flat).reshape(B, 64, OH, OW)
+    feats, k = [], 0
+    for li, (nblk, stride) in enumerate(((3, 1), (4, 2), (6, 2), (3, 2)), start=1):
+        for bi in range(nblk):
+            key, st = f"layer{li}.{bi}", (stride if bi == 0 else 1)
+            m1, m2, m3 = masks[k]
+            k += 1
+            a1 = O.batch_norm(sd, key + ".bn1", F.conv2d(cur, sd[key + ".conv1.weight"]), True) * m1
+            a2 = O.batch_norm(sd, key + ".bn2", F.conv2d(a1, sd[key + ".conv2.weight"], stride=st, padding=1), True) * m2
+            o3 = O.batch_norm(sd, key + ".bn3", F.conv2d(a2, sd[key + ".conv3.weight"]), True)
+            res = cur
+            if key + ".downsample.0.weight" in sd:
+                res = O.batch_norm(sd, key + ".downsample.1", F.conv2d(cur, sd[key + ".downsample.0.weight"], stride=st), True)
+            cur = (o3 + res) * m3
+        feats.append(cur)
+    pooled = cur.mean((2, 3)) * mpool
+    f64 = F.linear(pooled, sd["fc1.weight"], sd["fc1.bias"]) * mfeat
+    fwd = {"feat": rel_err(feat, f64.detach()), "x2": rel_err(x2, feats[1].detach()), "x4": rel_err(x4, cur.detach())}
+    print("forward against fp64 with the run's patterns:", fwd)
+    # (fp32 rounding through 53 convolutions and BatchNorms whose 7 x 7 statistics see 588 samples per channel at this batch)
+    assert fwd["x2"] < 2e-5 and fwd["x4"] < 3e-4 and fwd["feat"] < 3e-4, fwd
+    ((f64 * cot_f.double()).sum() + (feats[1] * cot_2.double()).sum()).backward()
+    rows = {name: rel_err(got[name], p.grad) for name, p in leaves.items()}
+    worst = max(rows, key=rows.get)
+    print("backbone gradients against fp64 with the run's patterns: worst", worst, rows[worst], "median",
+          float(np.median(list(rows.values()))))
+    assert set(rows) == set(got)
+    assert rows[worst] < 2e-4, (worst, rows[worst], sorted(rows.items(), key=lambda kv: -kv[1])[:6])
