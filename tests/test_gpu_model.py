@@ -1149,3 +1149,123 @@ def test_backbone_gradients_against_fp64_with_the_runs_own_patterns():
           float(np.median(list(rows.values()))))
     assert set(rows) == set(got)
     assert rows[worst] < 2e-4, (worst, rows[worst], sorted(rows.items(), key=lambda kv: -kv[1])[:6])
+
+
+@pytest.mark.timeout(1500)
+def test_hrnet_gradients_against_fp64_with_the_runs_own_patterns():
+    """HRNet-W32 (models/hrnet.py:150-261; BASELINE configs[3]'s backbone) the same way as the ResNet above: forward and
+    backward through the real module tree (fused BasicBlocks, conv + BatchNorm + ReLU units, exchange units on their branch
+    streams, layer1 on the Bottleneck executor), every ReLU's sign pattern taken from the HIP run — bn -> relu pairs from the
+    raw convolution output and the scale / shift the kernels used, residual and exchange ReLUs from the stored outputs —
+    and the oracle's layers (oracle/scat_oracle.py hrnet_forward, restated here with a mask where it has F.relu) evaluated in
+    fp64 with them.  Every parameter gradient of the network then has to agree to rounding; against the reference's goldens
+    the inner ones are held to 0.25 (test_hrnet_golden)."""
+    import torch.nn.functional as F
+    from scat_amd.models import hrnet as H
+    from scat_amd.models import resnet as R
+
+    B = 2
+    net = H.HRNet(c=32, nof_joints=128, bn_momentum=0.1)
+    full = synth.to_torch(synth.fill_state(111, net.state_dict()))
+    net.load_state_dict(full, strict=True)
+    net.cuda().train()
+    mods = dict(net.named_modules())
+    x = T(synth.images(112, B))
+    cot = T(synth.normal_like(113, "cot", (B, 128, 56, 56)))
+
+    bnrec, outrec = {}, {}
+
+    class RecState(R._BNState):
+        __slots__ = ()
+
+        def __init__(self, c, bn, training):
+            super().__init__(c, bn, training)
+            bnrec[id(bn)] = (c, self.scale, self.shift)
+
+    hooks = []
+    for name, m in mods.items():
+        if isinstance(m, (H.BasicBlock, H.Bottleneck, H.StageModule)):
+            hooks.append(m.register_forward_hook(lambda mod, inp, out, name=name: outrec.__setitem__(name, out)))
+    orig = R._BNState
+    R._BNState = RecState
+    try:
+        y = net(x.cuda())
+        (y * cot.cuda()).sum().backward()
+    finally:
+        R._BNState = orig
+        for h in hooks:
+            h.remove()
+    torch.cuda.synchronize()
+    got = {k: p.grad.detach().cpu().double() for k, p in net.named_parameters()}
+
+    def bn_mask(kb):
+        c, sc, sh = bnrec[id(mods[kb])]
+        return (c.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) > 0).cpu()
+
+    def out_mask(key, i=None):
+        o = outrec[key]
+        return ((o if i is None else o[i]) > 0).cpu()
+
+    sd = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in full.items()}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+
+    def cbn(kc, kb, t, stride=1, pad=1, relu=False):
+        z = O.batch_norm(sd, kb, F.conv2d(t, sd[kc + ".weight"], stride=stride, padding=pad), True)
+        return z * bn_mask(kb) if relu else z
+
+    def basic(key, t):
+        o = cbn(key + ".conv1", key + ".bn1", t, relu=True)
+        o = cbn(key + ".conv2", key + ".bn2", o)
+        return (o + t) * out_mask(key)
+
+    def stage_module(key, xs, stage, out_branches):
+        xs = list(xs)
+        for i in range(stage):
+            for b in range(4):
+                xs[i] = basic(f"{key}.branches.{i}.{b}", xs[i])
+        fused = []
+        for i in range(out_branches):
+            acc = None
+            for j in range(stage):
+                fk = f"{key}.fuse_layers.{i}.{j}"
+                if i == j:
+                    t = xs[j]
+                elif i < j:
+                    t = F.interpolate(cbn(fk + ".0", fk + ".1", xs[j], pad=0), scale_factor=float(2 ** (j - i)), mode="nearest")
+                else:
+                    t = xs[j]
+                    for k in range(i - j):
+                        t = cbn(f"{fk}.{k}.0", f"{fk}.{k}.1", t, stride=2, relu=(k < i - j - 1))
+                acc = t if acc is None else acc + t
+            fused.append(acc * out_mask(key, i))
+        return fused
+
+    t = cbn("conv1", "bn1", x.double(), stride=2, relu=True)
+    t = cbn("conv2", "bn2", t, stride=2, relu=True)
+    for b in range(4):
+        k = f"layer1.{b}"
+        o = cbn(k + ".conv1", k + ".bn1", t, pad=0, relu=True)
+        o = cbn(k + ".conv2", k + ".bn2", o, relu=True)
+        o = cbn(k + ".conv3", k + ".bn3", o, pad=0)
+        res = cbn(k + ".downsample.0", k + ".downsample.1", t, pad=0) if (k + ".downsample.0.weight") in sd else t
+        t = (o + res) * out_mask(k)
+    xs = [cbn("transition1.0.0", "transition1.0.1", t, relu=True),
+          cbn("transition1.1.0.0", "transition1.1.0.1", t, stride=2, relu=True)]
+    xs = stage_module("stage2.0", xs, 2, 2)
+    xs = [xs[0], xs[1], cbn("transition2.2.0.0", "transition2.2.0.1", xs[-1], stride=2, relu=True)]
+    for m in range(4):
+        xs = stage_module(f"stage3.{m}", xs, 3, 3)
+    xs = [xs[0], xs[1], xs[2], cbn("transition3.3.0.0", "transition3.3.0.1", xs[-1], stride=2, relu=True)]
+    xs = stage_module("stage4.0", xs, 4, 4)
+    xs = stage_module("stage4.1", xs, 4, 4)
+    xs = stage_module("stage4.2", xs, 4, 1)
+    y64 = F.conv2d(xs[0], sd["final_layer.weight"], sd["final_layer.bias"])
+    fwd = rel_err(y, y64.detach())
+    (y64 * cot.double()).sum().backward()
+    rows = {name: rel_err(got[name], p.grad) for name, p in leaves.items()}
+    worst = max(rows, key=rows.get)
+    print("HRNet-W32 against fp64 with the run's patterns: forward", fwd, "gradients: worst", worst, rows[worst], "median",
+          float(np.median(list(rows.values()))), "of", len(rows))
+    assert set(rows) == set(got)
+    assert fwd < 1e-4, fwd
+    assert rows[worst] < 3e-4, (worst, rows[worst], sorted(rows.items(), key=lambda kv: -kv[1])[:6])      # (measured 1.0e-4)
