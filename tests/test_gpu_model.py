@@ -1269,3 +1269,109 @@ def test_hrnet_gradients_against_fp64_with_the_runs_own_patterns():
     assert set(rows) == set(got)
     assert fwd < 1e-4, fwd
     assert rows[worst] < 3e-4, (worst, rows[worst], sorted(rows.items(), key=lambda kv: -kv[1])[:6])      # (measured 1.0e-4)
+
+
+@pytest.mark.timeout(1500)
+def test_train_step_gradients_against_fp64_with_the_runs_own_patterns():
+    """One whole train.py iteration of BASELINE configs[1]'s network (train.py:152-209: forward with the mask-token draw, the
+    loss, backward; batch 8 here) — the real TrainStep: split backbone with the token path on its own stream, weight
+    gradients on the side stream, flat buckets — against the oracle's EncoderTransformer in fp64 whose backbone is evaluated
+    with the HIP run's ReLU sign patterns and max-pool taps (as in test_backbone_gradients_against_fp64_with_the_runs_own_patterns;
+    the head has no piecewise-linear piece).  Prediction, loss and EVERY parameter gradient, head and backbone."""
+    import torch.nn.functional as F
+    from scat_amd import ops as OPS
+    from scat_amd.models import resnet as R
+    from scat_amd.trainer import TrainStep
+
+    B = 8
+    x, lab = T(synth.images(72, B)), T(synth.labels(73, B))
+    net = make_encoder(1)
+    net.train()
+    ts = TrainStep(net, lr=5e-4)
+    recs, stem, relus = [], {}, []
+    bf, mp, rl = R._block_forward, OPS.maxpool_fwd, OPS.relu_fwd
+
+    def bf_rec(*a, **k):
+        rec = bf(*a, **k)
+        recs.append(rec)
+        return rec
+
+    def mp_rec(c0, scale=None, shift=None, relu=False):
+        y, idx = mp(c0, scale, shift, relu)
+        stem.update(c0=c0, scale=scale, shift=shift, idx=idx)
+        return y, idx
+
+    def rl_rec(t):
+        y = rl(t)
+        relus.append(y)
+        return y
+
+    R._block_forward, OPS.maxpool_fwd, OPS.relu_fwd = bf_rec, mp_rec, rl_rec
+    try:
+        random.seed(3)
+        total, parts, lpl, pred = ts(x.cuda(), lab.cuda())
+    finally:
+        R._block_forward, OPS.maxpool_fwd, OPS.relu_fwd = bf, mp, rl
+    torch.cuda.synchronize()
+    assert len(recs) == 16 and stem
+    feat_hip = [t for t in relus if tuple(t.shape) == (B, 1024)][-1]
+    g_hip = {k: p.grad.detach().cpu().double() for k, p in net.named_parameters() if p.grad is not None}
+
+    def fma_sign(c, s):
+        return (c.double() * s.scale.double().view(1, -1, 1, 1) + s.shift.double().view(1, -1, 1, 1) > 0).cpu()
+
+    m0 = (stem["c0"].double() * stem["scale"].double().view(1, -1, 1, 1) + stem["shift"].double().view(1, -1, 1, 1) > 0).cpu()
+    idx = stem["idx"].cpu().long()
+    OH, OW = idx.shape[2:]
+    oy, ox = torch.arange(OH).view(1, 1, OH, 1), torch.arange(OW).view(1, 1, 1, OW)
+    flat = ((2 * oy - 1 + idx // 3) * (2 * OW) + (2 * ox - 1 + idx % 3)).reshape(B, 64, -1)
+    masks = [(fma_sign(r[2], r[3]), fma_sign(r[4], r[5]), (r[10] > 0).cpu()) for r in recs]
+    mpool = (recs[-1][10].double().mean((2, 3)) > 0).cpu()
+    mfeat = (feat_hip > 0).cpu()
+
+    def resnet_with_patterns(sd, xin, prefix="", training=True):
+        p = prefix
+        a0 = O.batch_norm(sd, p + "bn1", F.conv2d(xin, sd[p + "conv1.weight"], stride=2, padding=3), True) * m0
+        cur = a0.reshape(B, 64, -1).gather(2, flat).reshape(B, 64, OH, OW)
+        feats, k = [], 0
+        for li, (nblk, stride) in enumerate(((3, 1), (4, 2), (6, 2), (3, 2)), start=1):
+            for bi in range(nblk):
+                key, st = f"{p}layer{li}.{bi}", (stride if bi == 0 else 1)
+                m1, m2, m3 = masks[k]
+                k += 1
+                a1 = O.batch_norm(sd, key + ".bn1", F.conv2d(cur, sd[key + ".conv1.weight"]), True) * m1
+                a2 = O.batch_norm(sd, key + ".bn2", F.conv2d(a1, sd[key + ".conv2.weight"], stride=st, padding=1), True) * m2
+                o3 = O.batch_norm(sd, key + ".bn3", F.conv2d(a2, sd[key + ".conv3.weight"]), True)
+                res = cur
+                if key + ".downsample.0.weight" in sd:
+                    res = O.batch_norm(sd, key + ".downsample.1",
+                                       F.conv2d(cur, sd[key + ".downsample.0.weight"], stride=st), True)
+                cur = (o3 + res) * m3
+            feats.append(cur)
+        f = F.linear(cur.mean((2, 3)) * mpool, sd[p + "fc1.weight"], sd[p + "fc1.bias"]) * mfeat
+        return (f, *feats)
+
+    sd = {k: (v.double() if v.dtype == torch.float32 else v)
+          for k, v in synth.to_torch(synth.encoder_transformer_state(1, 8)).items()}
+    params = O.trainable(sd)
+    for p in params.values():
+        p.requires_grad_(True)
+    plain = O.resnet_forward
+    O.resnet_forward = resnet_with_patterns
+    try:
+        random.seed(3)
+        pr, fv, pl = O.encoder_transformer_forward(sd, T(synth.mean_params(1)).double(), x.double())
+    finally:
+        O.resnet_forward = plain
+    loss, *_ = O.scat_loss(pr, lab.double(), pl)
+    loss.backward()
+    g64 = {k: p.grad for k, p in params.items() if p.grad is not None}
+    assert rel_err(pred[:, 3:66], pr.detach()[:, 3:66]) < 2e-5
+    assert abs(total.item() - loss.item()) / abs(loss.item()) < 2e-5
+    assert set(g_hip) == set(g64)
+    rows = {k: rel_err(g_hip[k], g64[k]) for k in g64}
+    worst = max(rows, key=rows.get)
+    head = {k: v for k, v in rows.items() if not k.startswith("main_encoder.")}
+    print("train step against fp64 with the run's patterns: gradients worst", worst, rows[worst], "median",
+          float(np.median(list(rows.values()))), "head worst", max(head.values()), "of", len(rows))
+    assert rows[worst] < 5e-4, (worst, rows[worst], sorted(rows.items(), key=lambda kv: -kv[1])[:6])
