@@ -1271,10 +1271,12 @@ def test_hrnet_gradients_against_fp64_with_the_runs_own_patterns():
     assert rows[worst] < 3e-4, (worst, rows[worst], sorted(rows.items(), key=lambda kv: -kv[1])[:6])      # (measured 1.0e-4)
 
 
-@pytest.mark.timeout(1500)
-def test_train_step_gradients_against_fp64_with_the_runs_own_patterns():
+@pytest.mark.timeout(1700)
+@pytest.mark.parametrize("B", [8, 96])
+def test_train_step_gradients_against_fp64_with_the_runs_own_patterns(B):
     """One whole train.py iteration of BASELINE configs[1]'s network (train.py:152-209: forward with the mask-token draw, the
-    loss, backward; batch 8 here) — the real TrainStep: split backbone with the token path on its own stream, weight
+    loss, backward; at batch 8 and at the benchmarked batch 96, whose tile plans, split-K factors and epilogue reductions exist
+    only at that size) — the real TrainStep: split backbone with the token path on its own stream, weight
     gradients on the side stream, flat buckets — against the oracle's EncoderTransformer in fp64 whose backbone is evaluated
     with the HIP run's ReLU sign patterns and max-pool taps (as in test_backbone_gradients_against_fp64_with_the_runs_own_patterns;
     the head has no piecewise-linear piece).  Prediction, loss and EVERY parameter gradient, head and backbone."""
@@ -1283,7 +1285,6 @@ def test_train_step_gradients_against_fp64_with_the_runs_own_patterns():
     from scat_amd.models import resnet as R
     from scat_amd.trainer import TrainStep
 
-    B = 8
     x, lab = T(synth.images(72, B)), T(synth.labels(73, B))
     net = make_encoder(1)
     net.train()
